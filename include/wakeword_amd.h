@@ -1,0 +1,162 @@
+/*
+ * wakeword_amd.h -- C ABI of libwakeword_amd.so (MI355X / gfx950 native).
+ *
+ * The reference (sarpel/wakeword-jupyterlab) is pure Python and has no FFI: its boundary for the
+ * hot path is three Python call signatures.  Each entry point below names the reference code it
+ * replaces (paths relative to the reference repository).  The Python host layer
+ * (the .py files of wakeword-jupyterlab_amd) binds these with ctypes and re-exposes the reference signatures;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every `*_dev` pointer is a DEVICE pointer (HBM) on the current HIP device; every `*_host`
+ *     pointer is ordinary host memory.  No torch / C++ types cross this boundary.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All launch
+ *     functions are asynchronous on that stream, allocate nothing, never synchronise and are
+ *     therefore capturable into a hipGraph once ww_init() has run on the device.
+ *   - return value: WW_OK (0) or a negative WW_E* code; ww_last_error() gives the message of the
+ *     calling thread's most recent failure.  Nothing falls back to a CPU path: without a usable
+ *     gfx950 device every launch function fails with WW_ENODEVICE.
+ *   - all tensors are float32, C-contiguous in the stated shape unless a stride is a parameter.
+ */
+#ifndef WAKEWORD_AMD_H
+#define WAKEWORD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WW_ABI_VERSION 1
+
+#if defined(WW_BUILD)
+#define WW_API __attribute__((visibility("default")))
+#else
+#define WW_API
+#endif
+
+#define WW_OK 0
+#define WW_EINVAL (-1)    /* bad shape / alignment / argument */
+#define WW_ENODEVICE (-2) /* no HIP device, or not gfx950 */
+#define WW_EHIP (-3)      /* a HIP runtime call failed */
+#define WW_EUNSUPPORTED (-4)
+
+/* AudioConfig, wakeword_training_script.py:29-37 (dup wakeword_training.ipynb cell 3);
+ * Config, wakeword_training/train_wakeword.py:16-25; ModelConfig, wakeword_training_script.py:39-43 */
+#define WW_SAMPLE_RATE 16000
+#define WW_CLIP_SAMPLES 16000
+#define WW_N_FFT 2048
+#define WW_HOP 512
+#define WW_N_MELS 80
+#define WW_N_FRAMES 32 /* 1 + 16000/512, librosa center=True */
+#define WW_N_BINS 1025
+#define WW_HIDDEN 256
+#define WW_N_CLASSES 2
+#define WW_MAX_WIDTH 32 /* widest mel image (frames) the conv kernels take: T in [1, 32] */
+
+typedef void* ww_stream_t;
+
+/* ---- library / device ------------------------------------------------------------------- */
+WW_API int ww_abi_version(void);
+WW_API const char* ww_last_error(void);
+/* Build and upload the front-end tables (window, twiddles, sparse mel pieces) for the current
+ * device.  Idempotent.  Must have run once on a device before any launch below is captured into
+ * a hipGraph (it allocates and synchronises); the launch functions call it lazily otherwise. */
+WW_API int ww_init(void);
+/* Device facts used by bench.py for the roofline denominator: number of CUs, max clock (kHz). */
+WW_API int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len);
+
+/* ---- front-end tables, host side (no GPU needed; lets CPU tests check them) ------------------ */
+/* librosa.filters.mel(sr=16000, n_fft=2048, n_mels=80, fmin=0, fmax=8000, htk=False,
+ * norm='slaney') as used by wakeword_training_script.py:89-98 -> [80][1025] float32. */
+WW_API int ww_mel_filterbank_host(float* out_host);
+/* periodic Hann window of 2048 points (librosa.stft window='hann') -> [2048] float32. */
+WW_API int ww_hann_window_host(float* out_host);
+
+/* ---- K1: log-mel front-end --------------------------------------------------------------- */
+/* Replaces AudioProcessor.normalize_audio (:73-76), the zero-pad branch of pad_or_truncate
+ * (:78-83) and AudioProcessor.audio_to_mel (:85-101) =
+ * librosa.feature.melspectrogram + librosa.power_to_db(ref=np.max), batched.
+ *   pcm_dev      [n_clips] rows of `clip_len` valid samples, row i at pcm_dev + i*clip_stride
+ *                (floats; 16-byte aligned base, clip_stride % 4 == 0, 0 < clip_len <= 16000;
+ *                shorter rows are right-zero-padded like pad_or_truncate does)
+ *   normalize    != 0: divide the clip by max|x| first (process_audio_file order, :131-133);
+ *                a silent clip then yields NaN, as the reference does
+ *   logmel_dev   [n_clips][80][32]  (== the [B,1,80,32] tensor WakewordDataset.__getitem__ :204-216
+ *                returns, batched), dB in [-80, 0] with per-clip max exactly 0 */
+WW_API int ww_logmel_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, int64_t clip_len,
+                  int normalize, float* logmel_dev, ww_stream_t stream);
+
+/* ---- weights ------------------------------------------------------------------------------ */
+/* The reference state_dict (train_wakeword.py:28-36 / wakeword_training_script.py:141-165) as
+ * host pointers in torch layout.  conv3_* are NULL for SimpleWakewordModel.  weight_hh_l* are not
+ * part of the struct: with seq_len 1 and zero initial state they never reach the output. */
+typedef struct ww_state_dict {
+    int32_t n_conv;            /* 2 (SimpleWakewordModel) or 3 (WakewordModel) */
+    int32_t hidden;            /* 256 */
+    const float* conv_weight[3]; /* [32,1,3,3], [64,32,3,3], [128,64,3,3] */
+    const float* conv_bias[3];   /* [32], [64], [128] */
+    const float* lstm_weight_ih[2]; /* [4*hidden, C_last], [4*hidden, hidden]; gate order i,f,g,o */
+    const float* lstm_bias_ih[2];   /* [4*hidden] */
+    const float* lstm_bias_hh[2];   /* [4*hidden] */
+    const float* fc_weight;         /* [2, hidden] */
+    const float* fc_bias;           /* [2] */
+} ww_state_dict;
+
+/* Number of floats of the packed (kernel-layout) weight image for a model with n_conv convs. */
+WW_API int64_t ww_packed_weights_floats(int32_t n_conv);
+/* Pack on the host (pure CPU): MFMA B-operand order for the convs, transposed W_ih with the dead
+ * forget-gate rows dropped, b_ih + b_hh pre-summed.  The caller uploads `packed_host` to HBM once
+ * (model.load_state_dict / .to(device)) and passes the device copy to the functions below. */
+WW_API int ww_pack_weights_host(const ww_state_dict* sd, float* packed_host);
+
+/* ---- K2: conv stack + global average pool --------------------------------------------------- */
+/* Replaces `x = F.relu(self.conv1(x)); x = F.relu(self.conv2(x)); [conv3]; x = self.pool(x)`
+ * (train_wakeword.py:39-41 / wakeword_training_script.py:170-173).
+ *   mel_dev    [n][80][width]   (the [B,1,80,T] model input), 1 <= width <= 32
+ *   pooled_dev [n][C_last]      C_last = 64 (n_conv 2) or 128 (n_conv 3)
+ *   scratch_dev  n_conv 3 only: ww_cnn_scratch_bytes(n, 3) bytes; may be NULL for n_conv 2 */
+WW_API int64_t ww_cnn_scratch_bytes(int64_t n, int32_t n_conv);
+WW_API int ww_cnn_pool_f32(const float* mel_dev, int64_t n, int32_t width, const float* packed_dev,
+                    int32_t n_conv, void* scratch_dev, float* pooled_dev, ww_stream_t stream);
+
+/* ---- K3: 2-layer LSTM (one step, zero state) + Linear ---------------------------------------- */
+/* Replaces `lstm_out, _ = self.lstm(x.unsqueeze(1)); x = lstm_out[:, -1, :]; x = self.fc(x)`
+ * (train_wakeword.py:42-48 / wakeword_training_script.py:175-182), dropout = identity (eval).
+ *   pooled_dev [n][C_last] -> logits_dev [n][2] */
+WW_API int ww_lstm_fc_f32(const float* pooled_dev, int64_t n, const float* packed_dev, int32_t n_conv,
+                   float* logits_dev, ww_stream_t stream);
+
+/* ---- composed entry points ----------------------------------------------------------------- */
+/* model.forward(x): SimpleWakewordModel.forward train_wakeword.py:38-49 /
+ * WakewordModel.forward wakeword_training_script.py:167-184.  workspace >= ww_workspace_bytes. */
+WW_API int64_t ww_workspace_bytes(int64_t n, int32_t n_conv);
+WW_API int ww_model_forward_f32(const float* mel_dev, int64_t n, int32_t width, const float* packed_dev,
+                         int32_t n_conv, void* workspace_dev, float* logits_dev, ww_stream_t stream);
+/* PCM -> logits: the eval loop body of wakeword_training.ipynb cell 17 / validate()
+ * wakeword_training_script.py:269-289 with the Dataset's mel path folded in (K1 -> K2 -> K3). */
+WW_API int ww_forward_pcm_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, int64_t clip_len,
+                       int normalize, const float* packed_dev, int32_t n_conv, void* workspace_dev,
+                       float* logits_dev, ww_stream_t stream);
+
+/* ---- streaming: sliding 1 s window, one hop per step, many microphones ------------------------ */
+/* Semantics per window = predict_wakeword (wakeword_training.ipynb cell 19): normalise the last
+ * 16000 samples, log-mel, forward, softmax, p[wakeword].  The reference has no streaming code;
+ * this is that function applied to every hop of every microphone.
+ * The per-hop step (ring append -> K1 -> K2 -> K3 -> softmax) is captured once into a hipGraph and
+ * replayed by ww_streamer_step. */
+typedef struct ww_streamer ww_streamer;
+WW_API int ww_streamer_create(int32_t n_mics, int32_t hop_samples, const float* packed_dev, int32_t n_conv,
+                       ww_stream_t stream, ww_streamer** out);
+/* hop_dev [n_mics][hop_samples] new samples; prob_dev [n_mics] softmax p(wakeword) of the window
+ * ending at this hop; logits_dev (may be NULL) [n_mics][2]. */
+WW_API int ww_streamer_step(ww_streamer* s, const float* hop_dev, float* prob_dev, float* logits_dev);
+/* Copy of the current 1 s window of every mic, oldest sample first: [n_mics][16000] (for tests). */
+WW_API int ww_streamer_window(ww_streamer* s, float* window_dev);
+WW_API int ww_streamer_destroy(ww_streamer* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAKEWORD_AMD_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libwakeword_amd.so (the C ABI declared in include/wakeword_amd.h).
+
+The shared library is the ONLY implementation of the hot path: importing this module fails loudly
+when it has not been built (`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C wakeword-jupyterlab_amd/csrc`), and every launch fails with WW_ENODEVICE when no gfx950
+device is visible.  There is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# torch first: it carries its own libamdhip64 (SONAME libamdhip64.so.7).  Loading ours afterwards makes the
+# dynamic loader bind libwakeword_amd.so to that SAME runtime instance, so torch's streams, allocations and
+# device pointers are valid inside the library.  The other order would leave two HIP runtimes in the process.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwakeword_amd.so")
+
+WW_OK, WW_EINVAL, WW_ENODEVICE, WW_EHIP, WW_EUNSUPPORTED = 0, -1, -2, -3, -4
+ABI_VERSION = 1
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libwakeword_amd: {msg} (code {code})")
+        self.code = code
+
+
+class StateDict(C.Structure):
+    """struct ww_state_dict (include/wakeword_amd.h)."""
+    _fields_ = [
+        ("n_conv", C.c_int32), ("hidden", C.c_int32),
+        ("conv_weight", C.c_void_p * 3), ("conv_bias", C.c_void_p * 3),
+        ("lstm_weight_ih", C.c_void_p * 2), ("lstm_bias_ih", C.c_void_p * 2), ("lstm_bias_hh", C.c_void_p * 2),
+        ("fc_weight", C.c_void_p), ("fc_bias", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+PROTOTYPES = {
+    "ww_abi_version": (C.c_int, []),
+    "ww_last_error": (C.c_char_p, []),
+    "ww_init": (C.c_int, []),
+    "ww_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "ww_mel_filterbank_host": (C.c_int, [C.c_void_p]),
+    "ww_hann_window_host": (C.c_int, [C.c_void_p]),
+    "ww_logmel_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "ww_packed_weights_floats": (C.c_int64, [C.c_int32]),
+    "ww_pack_weights_host": (C.c_int, [C.POINTER(StateDict), C.c_void_p]),
+    "ww_cnn_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "ww_cnn_pool_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ww_lstm_fc_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ww_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "ww_model_forward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ww_forward_pcm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ww_streamer_create": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ww_streamer_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ww_streamer_window": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ww_streamer_destroy": (C.c_int, [C.c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library is the only implementation of this path (no CPU "
+            "fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C wakeword-jupyterlab_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    if lib.ww_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI {lib.ww_abi_version()} != expected {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> int:
+    """Raise NativeError on a negative return code; pass sizes / WW_OK through."""
+    if rc < 0:
+        raise NativeError(rc, (lib.ww_last_error() or b"").decode("utf-8", "replace"))
+    return rc
+
+
+def device_info():
+    n_cu, khz = C.c_int(0), C.c_int(0)
+    name = C.create_string_buffer(128)
+    check(lib.ww_device_info(C.byref(n_cu), C.byref(khz), name, 128))
+    return {"n_cu": n_cu.value, "clock_khz": khz.value, "name": name.value.decode()}

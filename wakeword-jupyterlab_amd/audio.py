@@ -1,0 +1,154 @@
+"""AudioProcessor drop-in (reference: /root/reference/wakeword_training_script.py:61-138).
+
+Same method names, arguments and return conventions:
+  load_audio(path)            -> float32 ndarray at 16 kHz mono, or None (prints the error; never raises)
+  normalize_audio(audio)      -> audio / max|audio|            (empty-array guard only, as the reference)
+  pad_or_truncate(audio, n)   -> random crop (python `random`) or right zero-pad
+  audio_to_mel(audio)         -> ndarray [80, 32] log-mel dB     <- HIP kernel K1
+  process_audio_file(path)    -> ndarray [80, 32] or None
+
+plus the batched form the GPU wants: `mel_batch(pcm[B, n]) -> torch.Tensor [B, 1, 80, 32]` on the device.
+
+`augment_audio` (train-only librosa pitch-shift / time-stretch) is out of scope and raises.
+`load_audio` decodes PCM / float WAV with the standard library and resamples with scipy's polyphase
+filter -- NOT librosa's decoder + soxr resampler; moving decode+resample to the GPU is the first
+"next" row.
+"""
+from __future__ import annotations
+
+import random
+import wave
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import AudioConfig, check_audio_config
+
+
+def _read_wav(path: str):
+    """Minimal RIFF/WAVE reader: 8/16/24/32-bit PCM and 32-bit float, any channel count -> (float32 [n, ch], sr)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError("not a RIFF/WAVE file")
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], int.from_bytes(data[pos + 4:pos + 8], "little")
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, sr = int.from_bytes(body[0:2], "little"), int.from_bytes(body[2:4], "little"), int.from_bytes(body[4:8], "little")
+            bits = int.from_bytes(body[14:16], "little")
+            if tag == 0xFFFE and len(body) >= 26:          # WAVE_FORMAT_EXTENSIBLE: real tag in the GUID
+                tag = int.from_bytes(body[24:26], "little")
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise ValueError("missing fmt/data chunk")
+    tag, ch, sr, bits = fmt
+    if tag == 1 and bits == 8:
+        x = (np.frombuffer(pcm, np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif tag == 1 and bits == 16:
+        x = np.frombuffer(pcm[: len(pcm) // 2 * 2], "<i2").astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(pcm[: len(pcm) // 3 * 3], np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (np.where(v >= 1 << 23, v - (1 << 24), v)).astype(np.float32) / float(1 << 23)
+    elif tag == 1 and bits == 32:
+        x = np.frombuffer(pcm[: len(pcm) // 4 * 4], "<i4").astype(np.float32) / float(1 << 31)
+    elif tag == 3 and bits == 32:
+        x = np.frombuffer(pcm[: len(pcm) // 4 * 4], "<f4").astype(np.float32)
+    elif tag == 3 and bits == 64:
+        x = np.frombuffer(pcm[: len(pcm) // 8 * 8], "<f8").astype(np.float32)
+    else:
+        raise ValueError(f"unsupported WAV encoding tag={tag} bits={bits}")
+    x = x[: len(x) // ch * ch].reshape(-1, ch)
+    return x, sr
+
+
+class AudioProcessor:
+    def __init__(self, config=AudioConfig, device=None):
+        check_audio_config(config)
+        self.config = config
+        self.device = torch.device(device) if device is not None else None
+
+    def _dev(self):
+        if self.device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("AudioProcessor.audio_to_mel runs on the MI355X only and no GPU is visible (no CPU fallback)")
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        return self.device
+
+    # ---- reference API --------------------------------------------------------------------------
+    def load_audio(self, file_path):
+        try:
+            x, sr = _read_wav(file_path)
+            audio = x.mean(axis=1) if x.shape[1] > 1 else x[:, 0]           # librosa.load mono=True
+            if sr != self.config.SAMPLE_RATE:
+                from math import gcd
+                from scipy.signal import resample_poly
+                g = gcd(int(sr), int(self.config.SAMPLE_RATE))
+                audio = resample_poly(audio.astype(np.float64), self.config.SAMPLE_RATE // g, sr // g)
+            return np.ascontiguousarray(audio, dtype=np.float32)
+        except Exception as e:                                             # reference: print and return None (:66-71)
+            print(f"Error loading {file_path}: {e}")
+            return None
+
+    def normalize_audio(self, audio):
+        if len(audio) == 0:
+            return audio
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return audio / np.max(np.abs(audio))
+
+    def pad_or_truncate(self, audio, target_length):
+        if len(audio) > target_length:
+            start_idx = random.randint(0, len(audio) - target_length)
+            return audio[start_idx:start_idx + target_length]
+        return np.pad(audio, (0, target_length - len(audio)), mode="constant")
+
+    def audio_to_mel(self, audio):
+        """[n <= 16000] samples -> ndarray [80, 32] (dB).  No normalisation here (reference :85-101)."""
+        n_frames = int(self.config.SAMPLE_RATE * self.config.DURATION / self.config.HOP_LENGTH) + 1
+        if len(audio) == 0:
+            return np.zeros((self.config.N_MELS, n_frames))
+        pcm = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).unsqueeze(0).to(self._dev())
+        return ops.logmel(pcm, False)[0, 0].cpu().numpy()
+
+    def augment_audio(self, audio, config=None):
+        raise NotImplementedError("augment_audio (train-only librosa pitch-shift/time-stretch, "
+                                  "wakeword_training_script.py:103-123) is outside the accelerated inference path")
+
+    def process_audio_file(self, file_path, augment=False):
+        audio = self.load_audio(file_path)
+        if audio is None:
+            return None
+        audio = self.normalize_audio(audio)
+        audio = self.pad_or_truncate(audio, int(self.config.SAMPLE_RATE * self.config.DURATION))
+        if augment:
+            audio = self.augment_audio(audio)
+        return self.audio_to_mel(audio)
+
+    # ---- batched form ---------------------------------------------------------------------------
+    def mel_batch(self, pcm, normalize: bool = True) -> torch.Tensor:
+        """pcm [B, n<=16000] (ndarray or tensor, any device) -> device tensor [B, 1, 80, 32].
+        normalize=True folds normalize_audio + zero-pad + audio_to_mel, the order process_audio_file uses."""
+        t = torch.as_tensor(pcm, dtype=torch.float32)
+        if t.device.type != "cuda":
+            t = t.to(self._dev(), non_blocking=True)
+        return ops.logmel(t, normalize)
+
+    def load_clips(self, paths, target_length=None):
+        """Decode, peak-normalise and crop/pad a list of files on the host, in the reference's order
+        (process_audio_file :125-138) -> (float32 [B, 16000], ok mask).  Feed to mel_batch(normalize=False)."""
+        n = target_length or int(self.config.SAMPLE_RATE * self.config.DURATION)
+        out = np.zeros((len(paths), n), dtype=np.float32)
+        ok = np.zeros(len(paths), dtype=bool)
+        for i, p in enumerate(paths):
+            a = self.load_audio(p)
+            if a is None:
+                continue
+            out[i] = self.pad_or_truncate(self.normalize_audio(a), n)
+            ok[i] = True
+        return out, ok

@@ -1,0 +1,319 @@
+// C ABI entry points of libwakeword_amd.so: argument checking, per-device table cache, the composed
+// PCM -> logits path and the hipGraph-captured streaming step.  Declared in include/wakeword_amd.h.
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "ww_internal.h"
+
+namespace ww {
+
+constexpr int kMaxDevices = 16;
+static std::mutex g_mu;
+static LogmelTables* g_tables[kMaxDevices] = {};
+static int g_cu[kMaxDevices] = {};
+static int g_checked[kMaxDevices] = {};   // 0 unknown, 1 gfx950, -1 refused
+
+static int current_device(int* dev) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(WW_ENODEVICE, "no HIP device visible: the HIP kernels are the only implementation of this path");
+    }
+    WW_HIP(hipGetDevice(dev));
+    if (*dev < 0 || *dev >= kMaxDevices) return fail(WW_EUNSUPPORTED, "device ordinal %d out of range", *dev);
+    return WW_OK;
+}
+
+int require_gfx950() {
+    int dev = 0;
+    if (int rc = current_device(&dev)) return rc;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_checked[dev] == 0) {
+        hipDeviceProp_t prop;
+        WW_HIP(hipGetDeviceProperties(&prop, dev));
+        g_cu[dev] = prop.multiProcessorCount;
+        g_checked[dev] = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : -1;
+    }
+    if (g_checked[dev] < 0) return fail(WW_ENODEVICE, "device %d is not gfx950 (MI355X): this library carries gfx950 code only", dev);
+    return WW_OK;
+}
+
+int device_cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    return g_cu[dev] > 0 ? g_cu[dev] : 256;
+}
+
+const LogmelTables* device_tables() {
+    int dev = 0;
+    if (require_gfx950() != WW_OK) return nullptr;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_tables[dev]) return g_tables[dev];
+    LogmelTables* host = new (std::nothrow) LogmelTables;
+    if (!host) { fail(WW_EHIP, "out of host memory"); return nullptr; }
+    const int pieces = build_logmel_tables(host);
+    if (pieces < 0) { delete host; return nullptr; }
+    LogmelTables* devp = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&devp), sizeof(LogmelTables));
+    if (e == hipSuccess) e = hipMemcpy(devp, host, sizeof(LogmelTables), hipMemcpyHostToDevice);
+    delete host;
+    if (e != hipSuccess) {
+        fail(WW_EHIP, "uploading the log-mel tables failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    g_tables[dev] = devp;
+    return devp;
+}
+
+static int64_t align256(int64_t b) { return (b + 255) & ~int64_t(255); }
+int64_t cnn_scratch_bytes(int64_t n, int n_conv);
+
+struct Workspace {
+    float* logmel;
+    float* pooled;
+    void* scratch;
+    int64_t total;
+};
+static Workspace carve(void* base, int64_t n, int n_conv) {
+    Workspace w{};
+    char* p = static_cast<char*>(base);
+    int64_t o = 0;
+    w.logmel = reinterpret_cast<float*>(p + o); o += align256(n * kMels * kFrames * int64_t(sizeof(float)));
+    w.pooled = reinterpret_cast<float*>(p + o); o += align256(n * 128 * int64_t(sizeof(float)));
+    w.scratch = p + o; o += align256(cnn_scratch_bytes(n, n_conv));
+    w.total = o;
+    return w;
+}
+
+static int check_pcm(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len) {
+    if (n_clips < 0 || n_clips > (int64_t(1) << 30)) return fail(WW_EINVAL, "n_clips %lld out of range", (long long)n_clips);
+    if (n_clips == 0) return WW_OK;
+    if (!pcm) return fail(WW_EINVAL, "null pcm pointer");
+    if (clip_len <= 0 || clip_len > kClip)
+        return fail(WW_EINVAL, "clip_len %lld: expected 1..%d samples (longer clips are cropped by the host, "
+                    "pad_or_truncate wakeword_training_script.py:78-83)", (long long)clip_len, kClip);
+    if (clip_stride < clip_len && n_clips > 1) return fail(WW_EINVAL, "clip_stride %lld < clip_len %lld", (long long)clip_stride, (long long)clip_len);
+    if ((reinterpret_cast<uintptr_t>(pcm) & 15) || (clip_stride & 3))
+        return fail(WW_EINVAL, "pcm must be 16-byte aligned with clip_stride %% 4 == 0 (got %p, %lld)", (const void*)pcm, (long long)clip_stride);
+    return WW_OK;
+}
+
+static int check_model(int64_t n, int32_t width, const float* packed, int32_t n_conv) {
+    if (n < 0 || n > (int64_t(1) << 30)) return fail(WW_EINVAL, "batch %lld out of range", (long long)n);
+    if (n_conv != 2 && n_conv != 3) return fail(WW_EINVAL, "n_conv must be 2 or 3, got %d", n_conv);
+    if (width < 1 || width > WW_MAX_WIDTH) return fail(WW_EUNSUPPORTED, "mel width %d: the conv kernels take 1..%d frames", width, WW_MAX_WIDTH);
+    if (n > 0 && (!packed || (reinterpret_cast<uintptr_t>(packed) & 15))) return fail(WW_EINVAL, "packed weights must be a 16-byte aligned device pointer");
+    return WW_OK;
+}
+
+}  // namespace ww
+
+using namespace ww;
+
+// --------------------------------------------------------------------------------------------------
+// streaming
+// --------------------------------------------------------------------------------------------------
+struct ww_streamer {
+    int n_mics, hop, n_conv;
+    const float* packed;
+    hipStream_t stream;
+    float* ring;         // [n_mics][16000]
+    int32_t* pos;        // device: index of the oldest sample (== next write position)
+    void* workspace;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    const float* cap_hop;
+    float* cap_prob;
+    float* cap_logits;
+    float* own_logits;   // used when the caller passes logits_dev == NULL
+};
+
+__global__ void ring_append_kernel(float* __restrict__ ring, const int32_t* __restrict__ pos_p,
+                                   const float* __restrict__ hop, int n_mics, int hop_len) {
+    const int pos = *pos_p;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_mics * hop_len; i += gridDim.x * blockDim.x) {
+        const int m = i / hop_len, k = i - m * hop_len;
+        int at = pos + k;
+        if (at >= kClip) at -= kClip;
+        ring[int64_t(m) * kClip + at] = hop[i];
+    }
+}
+__global__ void ring_advance_kernel(int32_t* pos_p, int hop_len) {
+    int p = *pos_p + hop_len;
+    *pos_p = p >= kClip ? p - kClip : p;
+}
+__global__ void ring_unroll_kernel(const float* __restrict__ ring, const int32_t* __restrict__ pos_p,
+                                   float* __restrict__ out, int n_mics) {
+    const int pos = *pos_p;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < int64_t(n_mics) * kClip;
+         i += int64_t(gridDim.x) * blockDim.x) {
+        const int m = int(i / kClip), k = int(i - int64_t(m) * kClip);
+        int at = pos + k;
+        if (at >= kClip) at -= kClip;
+        out[i] = ring[int64_t(m) * kClip + at];
+    }
+}
+
+static int streamer_enqueue(ww_streamer* s, const float* hop_dev, float* prob_dev, float* logits_dev) {
+    const int threads = 256;
+    const int blocks = (s->n_mics * s->hop + threads - 1) / threads;
+    hipLaunchKernelGGL(ring_append_kernel, dim3(blocks), dim3(threads), 0, s->stream, s->ring, s->pos, hop_dev, s->n_mics, s->hop);
+    hipLaunchKernelGGL(ring_advance_kernel, dim3(1), dim3(1), 0, s->stream, s->pos, s->hop);
+    WW_HIP(hipGetLastError());
+    Workspace w = carve(s->workspace, s->n_mics, s->n_conv);
+    if (int rc = launch_logmel(s->ring, s->n_mics, kClip, kClip, 1, s->pos, kClip, w.logmel, s->stream)) return rc;
+    if (int rc = launch_cnn_pool(w.logmel, s->n_mics, kFrames, s->packed, s->n_conv, w.scratch, w.pooled, s->stream)) return rc;
+    return launch_lstm_fc(w.pooled, s->n_mics, s->packed, s->n_conv, logits_dev, prob_dev, s->stream);
+}
+
+extern "C" {
+
+int ww_init(void) {
+    if (int rc = require_gfx950()) return rc;
+    return device_tables() ? WW_OK : WW_EHIP;
+}
+
+int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len) {
+    if (int rc = require_gfx950()) return rc;
+    int dev = 0;
+    WW_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    WW_HIP(hipGetDeviceProperties(&prop, dev));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (name && name_len > 0) std::snprintf(name, size_t(name_len), "%s (%s)", prop.name, prop.gcnArchName);
+    return WW_OK;
+}
+
+int ww_logmel_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
+                  float* logmel_dev, ww_stream_t stream) {
+    if (int rc = check_pcm(pcm_dev, n_clips, clip_stride, clip_len)) return rc;
+    if (n_clips > 0 && !logmel_dev) return fail(WW_EINVAL, "null output pointer");
+    if (int rc = require_gfx950()) return rc;
+    return launch_logmel(pcm_dev, n_clips, clip_stride, clip_len, normalize, nullptr, 0, logmel_dev,
+                         static_cast<hipStream_t>(stream));
+}
+
+int64_t ww_cnn_scratch_bytes(int64_t n, int32_t n_conv) { return cnn_scratch_bytes(n, n_conv); }
+
+int ww_cnn_pool_f32(const float* mel_dev, int64_t n, int32_t width, const float* packed_dev, int32_t n_conv,
+                    void* scratch_dev, float* pooled_dev, ww_stream_t stream) {
+    if (int rc = check_model(n, width, packed_dev, n_conv)) return rc;
+    if (n > 0 && (!mel_dev || !pooled_dev)) return fail(WW_EINVAL, "null tensor pointer");
+    if (int rc = require_gfx950()) return rc;
+    return launch_cnn_pool(mel_dev, n, width, packed_dev, n_conv, scratch_dev, pooled_dev, static_cast<hipStream_t>(stream));
+}
+
+int ww_lstm_fc_f32(const float* pooled_dev, int64_t n, const float* packed_dev, int32_t n_conv, float* logits_dev,
+                   ww_stream_t stream) {
+    if (int rc = check_model(n, 1, packed_dev, n_conv)) return rc;
+    if (n > 0 && (!pooled_dev || !logits_dev)) return fail(WW_EINVAL, "null tensor pointer");
+    if (int rc = require_gfx950()) return rc;
+    return launch_lstm_fc(pooled_dev, n, packed_dev, n_conv, logits_dev, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int64_t ww_workspace_bytes(int64_t n, int32_t n_conv) {
+    if (n < 0 || (n_conv != 2 && n_conv != 3)) return fail(WW_EINVAL, "bad workspace query");
+    return carve(nullptr, n, n_conv).total;
+}
+
+int ww_model_forward_f32(const float* mel_dev, int64_t n, int32_t width, const float* packed_dev, int32_t n_conv,
+                         void* workspace_dev, float* logits_dev, ww_stream_t stream) {
+    if (int rc = check_model(n, width, packed_dev, n_conv)) return rc;
+    if (n == 0) return WW_OK;
+    if (!mel_dev || !logits_dev || !workspace_dev) return fail(WW_EINVAL, "null tensor / workspace pointer");
+    if (int rc = require_gfx950()) return rc;
+    Workspace w = carve(workspace_dev, n, n_conv);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = launch_cnn_pool(mel_dev, n, width, packed_dev, n_conv, w.scratch, w.pooled, st)) return rc;
+    return launch_lstm_fc(w.pooled, n, packed_dev, n_conv, logits_dev, nullptr, st);
+}
+
+int ww_forward_pcm_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
+                       const float* packed_dev, int32_t n_conv, void* workspace_dev, float* logits_dev,
+                       ww_stream_t stream) {
+    if (int rc = check_pcm(pcm_dev, n_clips, clip_stride, clip_len)) return rc;
+    if (int rc = check_model(n_clips, kFrames, packed_dev, n_conv)) return rc;
+    if (n_clips == 0) return WW_OK;
+    if (!logits_dev || !workspace_dev) return fail(WW_EINVAL, "null logits / workspace pointer");
+    if (int rc = require_gfx950()) return rc;
+    Workspace w = carve(workspace_dev, n_clips, n_conv);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = launch_logmel(pcm_dev, n_clips, clip_stride, clip_len, normalize, nullptr, 0, w.logmel, st)) return rc;
+    if (int rc = launch_cnn_pool(w.logmel, n_clips, kFrames, packed_dev, n_conv, w.scratch, w.pooled, st)) return rc;
+    return launch_lstm_fc(w.pooled, n_clips, packed_dev, n_conv, logits_dev, nullptr, st);
+}
+
+int ww_streamer_create(int32_t n_mics, int32_t hop_samples, const float* packed_dev, int32_t n_conv,
+                       ww_stream_t stream, ww_streamer** out) {
+    if (!out) return fail(WW_EINVAL, "null out pointer");
+    *out = nullptr;
+    if (n_mics < 1 || n_mics > (1 << 20)) return fail(WW_EINVAL, "n_mics %d out of range", n_mics);
+    if (hop_samples < 4 || hop_samples > kClip || (hop_samples & 3) || (kClip % hop_samples))
+        return fail(WW_EINVAL, "hop_samples %d: must be a multiple of 4 that divides %d", hop_samples, kClip);
+    if (int rc = check_model(n_mics, kFrames, packed_dev, n_conv)) return rc;
+    if (!device_tables()) return WW_EHIP;   // also the gfx950 check; must precede graph capture
+    ww_streamer* s = new (std::nothrow) ww_streamer();
+    if (!s) return fail(WW_EHIP, "out of host memory");
+    s->n_mics = n_mics; s->hop = hop_samples; s->n_conv = n_conv; s->packed = packed_dev;
+    s->stream = static_cast<hipStream_t>(stream);
+    const int64_t ws = carve(nullptr, n_mics, n_conv).total;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->ring), sizeof(float) * int64_t(n_mics) * kClip);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->pos), 16);
+    if (e == hipSuccess) e = hipMalloc(&s->workspace, size_t(ws));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->own_logits), sizeof(float) * 2 * n_mics);
+    if (e == hipSuccess) e = hipMemsetAsync(s->ring, 0, sizeof(float) * int64_t(n_mics) * kClip, s->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->pos, 0, 16, s->stream);
+    if (e != hipSuccess) {
+        ww_streamer_destroy(s);
+        return fail(WW_EHIP, "streamer allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return WW_OK;
+}
+
+int ww_streamer_step(ww_streamer* s, const float* hop_dev, float* prob_dev, float* logits_dev) {
+    if (!s || !hop_dev || !prob_dev) return fail(WW_EINVAL, "null argument");
+    if (reinterpret_cast<uintptr_t>(hop_dev) & 3) return fail(WW_EINVAL, "hop_dev must be float-aligned");
+    float* lg = logits_dev ? logits_dev : s->own_logits;
+    if (!s->exec || s->cap_hop != hop_dev || s->cap_prob != prob_dev || s->cap_logits != lg) {
+        // (re)capture: the I/O pointers are baked into the graph's kernel nodes
+        if (s->exec) { (void)hipGraphExecDestroy(s->exec); s->exec = nullptr; }
+        if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+        WW_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = streamer_enqueue(s, hop_dev, prob_dev, lg);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(s->stream, &g);
+        if (rc != WW_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(WW_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        s->graph = g;
+        WW_HIP(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+        s->cap_hop = hop_dev; s->cap_prob = prob_dev; s->cap_logits = lg;
+    }
+    WW_HIP(hipGraphLaunch(s->exec, s->stream));
+    return WW_OK;
+}
+
+int ww_streamer_window(ww_streamer* s, float* window_dev) {
+    if (!s || !window_dev) return fail(WW_EINVAL, "null argument");
+    hipLaunchKernelGGL(ring_unroll_kernel, dim3(1024), dim3(256), 0, s->stream, s->ring, s->pos, window_dev, s->n_mics);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+int ww_streamer_destroy(ww_streamer* s) {
+    if (!s) return WW_OK;
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->ring) (void)hipFree(s->ring);
+    if (s->pos) (void)hipFree(s->pos);
+    if (s->workspace) (void)hipFree(s->workspace);
+    if (s->own_logits) (void)hipFree(s->own_logits);
+    delete s;
+    return WW_OK;
+}
+
+}  // extern "C"

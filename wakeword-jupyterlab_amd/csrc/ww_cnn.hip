@@ -1,0 +1,296 @@
+// K2: Conv2d(3x3, pad 1)+ReLU stack + global average pool on the f32 matrix cores.
+//
+// Replaces `F.relu(conv1) -> F.relu(conv2) [-> F.relu(conv3)] -> AdaptiveAvgPool2d((1,1))`
+// (/root/reference/wakeword_training/train_wakeword.py:39-41,
+//  /root/reference/wakeword_training_script.py:170-173).
+//
+// conv2 (32->64, 94.4 of the model's 96.5 MFLOP per clip) and conv3 (64->128) run as implicit GEMMs on
+// v_mfma_f32_32x32x2_f32 (exact f32, bit-for-bit an fmaf chain):
+//     M = the 32 columns of one image row   (A operand: activations, lane = column)
+//     N = 32 output channels                (B operand: weights, lane = channel)
+//     K = (input-channel pair, dy, dx)      2 channels per instruction
+// * the weights of a wave's N-tile (144 B-operand registers) are loaded ONCE per persistent workgroup
+//   and stay in VGPRs for every clip it processes: no weight re-reads at all;
+// * activations are read from an LDS tile [ci][row][34] with one ds_read_b32 per A register, and a
+//   register is reused for every (output row, dy) pair that touches its input row (6 reads feed 12 MFMAs);
+// * conv1 (1->32, 1.5 MFLOP) is recomputed per 8-row band on the VALU straight into that LDS tile, so
+//   conv1's 327 KB/clip output never exists in HBM;  bias+ReLU+pool are fused into the MFMA epilogue.
+//
+// Algorithmic flops per clip (T = 32): conv1 1,474,560 + conv2 94,371,840.
+#include "ww_internal.h"
+
+namespace ww {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kH = WW_N_MELS;      // image rows
+constexpr int kW = 32;             // image columns = lanes of an M-tile
+constexpr int kRS = 34;            // LDS row stride: columns -1..32
+constexpr int kMelRS = 36;         // mel tile row stride (rows -1..80, columns -1..34)
+constexpr int kBand = 8;           // conv2 output rows per band
+constexpr int kARows = kBand + 2;  // conv1 rows needed per band
+
+// LDS of the conv1+conv2 kernel (floats)
+constexpr int kActFloats = 32 * kARows * kRS;          // 10,880
+constexpr int kMelFloats = (kH + 2) * kMelRS;          // 2,952
+constexpr int kC2LdsFloats = kActFloats + kMelFloats + 4 * 32;
+
+__device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads) {
+    for (int i = tid; i < n; i += nthreads) p[i] = 0.f;
+}
+
+// conv1 for one band: act[ci][q][x+1] = relu(b1[ci] + sum w1[ci][dy][dx] * mel[y+dy-1][x+dx-1]),
+// y = y0 - 1 + q; zero where the position lies outside the image (that is conv2's zero padding).
+// wave w computes channels 8w..8w+7 (wave-uniform -> scalar weight loads); lane = (column, row parity).
+__device__ __forceinline__ void conv1_band(const float* __restrict__ melt, float* __restrict__ act,
+                                           const float* __restrict__ w1, const float* __restrict__ b1, int y0,
+                                           int width, int wave, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int i = 0; i < kARows / 2; ++i) {
+        const int q = 2 * i + h;
+        const int y = y0 - 1 + q;
+        const bool inside = (y >= 0) && (y < kH) && (x < width);
+        const float* m = melt + (inside ? y : 0) * kMelRS + x;     // rows y-1..y+1 -> tile rows y..y+2
+        const float m00 = m[0], m01 = m[1], m02 = m[2];
+        const float m10 = m[kMelRS], m11 = m[kMelRS + 1], m12 = m[kMelRS + 2];
+        const float m20 = m[2 * kMelRS], m21 = m[2 * kMelRS + 1], m22 = m[2 * kMelRS + 2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ci = 8 * wave + u;
+            const float* w = w1 + ci * 9;
+            float v = b1[ci];
+            v = fmaf(w[0], m00, v); v = fmaf(w[1], m01, v); v = fmaf(w[2], m02, v);
+            v = fmaf(w[3], m10, v); v = fmaf(w[4], m11, v); v = fmaf(w[5], m12, v);
+            v = fmaf(w[6], m20, v); v = fmaf(w[7], m21, v); v = fmaf(w[8], m22, v);
+            v = inside ? fmaxf(v, 0.f) : 0.f;
+            act[(ci * kARows + q) * kRS + x + 1] = v;
+        }
+    }
+}
+
+// 144 k-steps (16 channel pairs x 3 dx x 3 dy) over 4 output rows: 576 MFMAs, 288 LDS reads.
+// ap = &act[(h*ROWS + first input row)*kRS + x]; PLANE2 = floats between channel pair c and c+1.
+template <int ROWS>
+__device__ __forceinline__ void mfma_rows4(const float* __restrict__ ap, const float (&wb)[144], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            float a[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) a[q] = ap[(2 * c * ROWS + q) * kRS + dx];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r + dy], wb[(c * 3 + dy) * 3 + dx], acc[r], 0, 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1 + conv2 (+ pool | + store for the 3-conv model).  256 threads: wave = (row group rg, N-tile nt).
+// POOL : out = pooled [n][64]
+// !POOL: out = relu(conv2) as [n][80][64][32] (row, channel, column) for the conv3 kernel
+// ------------------------------------------------------------------------------------------------
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void cnn2_kernel(const float* __restrict__ mel, int n, int width,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ wB, const float* __restrict__ b2,
+                                                      float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* act = lds;                       // [32][10][34]
+    float* melt = act + kActFloats;         // [82][36]
+    float* red = melt + kMelFloats;         // [4][32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1, rg = wave >> 1;
+    const int x = lane & 31, h = lane >> 5;
+
+    float wb[144];
+#pragma unroll
+    for (int i = 0; i < 144; ++i) wb[i] = wB[(nt * 144 + i) * 64 + lane];
+    const float bias = b2[32 * nt + x];
+
+    zero_lds(lds, kC2LdsFloats, tid, 256);   // halos stay zero for the life of the workgroup
+    const float* ap = act + (h * kARows + rg * 4) * kRS + x;
+    const float inv_area = 1.0f / float(kH * width);
+
+    for (int clip = blockIdx.x; clip < n; clip += gridDim.x) {
+        __syncthreads();   // previous clip fully consumed (and the zero fill on the first trip)
+        const float* __restrict__ src = mel + int64_t(clip) * kH * width;
+        for (int i = tid; i < kH * width; i += 256) {
+            const int y = i / width, xx = i - y * width;
+            melt[(y + 1) * kMelRS + xx + 1] = src[i];
+        }
+        float pool = 0.f;
+        for (int band = 0; band < kH / kBand; ++band) {
+            const int y0 = band * kBand;
+            __syncthreads();   // mel tile ready / previous band's A reads retired
+            conv1_band(melt, act, w1, b1, y0, width, wave, lane);
+            __syncthreads();
+            f32x16 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+            mfma_rows4<kARows>(ap, wb, acc);
+            // D layout: lane&31 = channel, register j <-> column (j&3) + 8*(j>>2) + 4*(lane>>5)
+            if constexpr (POOL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
+                        const float v = fmaxf(acc[r][j] + bias, 0.f);
+                        pool += (col < width) ? v : 0.f;
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = y0 + rg * 4 + r;
+                    float* dst = out + ((int64_t(clip) * kH + y) * 64 + 32 * nt + x) * kW;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col0 = 8 * g + 4 * h;
+                        float4 v;
+                        v.x = (col0 + 0 < width) ? fmaxf(acc[r][4 * g + 0] + bias, 0.f) : 0.f;
+                        v.y = (col0 + 1 < width) ? fmaxf(acc[r][4 * g + 1] + bias, 0.f) : 0.f;
+                        v.z = (col0 + 2 < width) ? fmaxf(acc[r][4 * g + 2] + bias, 0.f) : 0.f;
+                        v.w = (col0 + 3 < width) ? fmaxf(acc[r][4 * g + 3] + bias, 0.f) : 0.f;
+                        *reinterpret_cast<float4*>(dst + col0) = v;
+                    }
+                }
+            }
+        }
+        if constexpr (POOL) {
+            pool += __shfl_xor(pool, 32);
+            __syncthreads();
+            if (lane < 32) red[wave * 32 + lane] = pool;
+            __syncthreads();
+            if (tid < 64) {
+                const int t_nt = tid >> 5, t_x = tid & 31;
+                const float s = red[t_nt * 32 + t_x] + red[(2 + t_nt) * 32 + t_x];   // row groups 0 and 1
+                out[int64_t(clip) * 64 + tid] = s * inv_area;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv3 (64->128) + ReLU + pool for the 3-conv WakewordModel.  512 threads: wave = (K-half kh, N-tile nt);
+// the two K-halves of an N-tile are summed through LDS before bias/ReLU.  Band = 4 output rows.
+// in = relu(conv2) as [n][80][64][32]; out = pooled [n][128].
+// ------------------------------------------------------------------------------------------------
+constexpr int kC3Rows = 6;
+constexpr int kC3ActFloats = 64 * kC3Rows * kRS;     // 13,056
+constexpr int kC3XchFloats = 4 * 4 * 16 * 64;        // [nt][r][j][lane] 16,384
+constexpr int kC3LdsFloats = kC3ActFloats + kC3XchFloats;
+
+__global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ in, int n, int width,
+                                                      const float* __restrict__ wB, const float* __restrict__ b3,
+                                                      float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* act = lds;                        // [64][6][34]
+    float* xch = act + kC3ActFloats;         // [4][4][16][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 3, kh = wave >> 2;
+    const int x = lane & 31, h = lane >> 5;
+
+    float wb[144];
+#pragma unroll
+    for (int i = 0; i < 144; ++i) wb[i] = wB[(nt * 288 + kh * 144 + i) * 64 + lane];
+    const float bias = b3[32 * nt + x];
+
+    zero_lds(lds, kC3ActFloats, tid, 512);
+    const float* ap = act + ((32 * kh + h) * kC3Rows) * kRS + x;
+    const float inv_area = 1.0f / float(kH * width);
+
+    for (int clip = blockIdx.x; clip < n; clip += gridDim.x) {
+        float pool = 0.f;
+        for (int band = 0; band < kH / 4; ++band) {
+            const int y0 = band * 4;
+            __syncthreads();   // previous band's reads of act / xch retired
+            // tile rows y0-1 .. y0+4; one image row = 64 channels x 32 columns contiguous in `in`
+#pragma unroll 1
+            for (int q = 0; q < kC3Rows; ++q) {
+                const int y = y0 - 1 + q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (y >= 0 && y < kH)
+                    v = *reinterpret_cast<const float4*>(in + (int64_t(clip) * kH + y) * (64 * kW) + tid * 4);
+                const int ci = tid >> 3, c0 = (tid & 7) * 4;
+                float* d = act + (ci * kC3Rows + q) * kRS + c0 + 1;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+            f32x16 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+            mfma_rows4<kC3Rows>(ap, wb, acc);
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xch[((nt * 4 + r) * 16 + j) * 64 + lane] = acc[r][j];
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
+                        const float v = fmaxf(acc[r][j] + xch[((nt * 4 + r) * 16 + j) * 64 + lane] + bias, 0.f);
+                        pool += (col < width) ? v : 0.f;
+                    }
+            }
+        }
+        if (kh == 0) {
+            pool += __shfl_xor(pool, 32);
+            if (lane < 32) out[int64_t(clip) * 128 + 32 * nt + lane] = pool * inv_area;
+        }
+    }
+}
+
+int64_t cnn_scratch_bytes(int64_t n, int n_conv) {
+    return n_conv == 3 ? n * int64_t(kH) * 64 * kW * int64_t(sizeof(float)) : 0;
+}
+
+int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
+                    float* pooled, hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    const PackedLayout L = packed_layout(n_conv);
+    const int64_t resident = int64_t(device_cu_count()) * 2;
+    const int grid = int(n < resident ? n : resident);
+    const size_t lds2 = sizeof(float) * kC2LdsFloats;
+    if (n_conv == 2) {
+        hipLaunchKernelGGL(cnn2_kernel<true>, dim3(grid), dim3(256), lds2, stream, mel, int(n), width,
+                           packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, pooled);
+        WW_HIP(hipGetLastError());
+        return WW_OK;
+    }
+    if (!scratch) return fail(WW_EINVAL, "n_conv == 3 needs ww_cnn_scratch_bytes() of scratch");
+    float* mid = static_cast<float*>(scratch);
+    hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid), dim3(256), lds2, stream, mel, int(n), width,
+                       packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, mid);
+    WW_HIP(hipGetLastError());
+    const int grid3 = int(n < device_cu_count() ? n : device_cu_count());
+    static bool lds_attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
+    if (!lds_attr_set) {
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   int(sizeof(float) * kC3LdsFloats)));
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(cnn3_kernel, dim3(grid3), dim3(512), sizeof(float) * kC3LdsFloats, stream, mid, int(n), width,
+                       packed + L.conv3_w, packed + L.conv3_b, pooled);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+}  // namespace ww

@@ -1,0 +1,95 @@
+// Internal definitions shared by the translation units of libwakeword_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wakeword_amd.h"
+
+namespace ww {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+int fail(int code, const char* fmt, ...);
+#define WW_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return ::ww::fail(WW_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                              __FILE__, __LINE__);                                           \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// K1 tables (one image per device, built on the host in double precision)
+// ---------------------------------------------------------------------------------------------
+constexpr int kClip = WW_CLIP_SAMPLES;
+constexpr int kNfft = WW_N_FFT;
+constexpr int kHop = WW_HOP;
+constexpr int kMels = WW_N_MELS;
+constexpr int kFrames = WW_N_FRAMES;
+constexpr int kBins = WW_N_BINS;
+
+// The mel matrix (2004 non-zeros, <=2 filters per bin, every filter one contiguous run of 9..75 bins)
+// is cut into fixed-size pieces of kPieceLen consecutive bins of ONE filter (zero-weight padded), so
+// that every lane of the mel stage runs the same trip count.
+constexpr int kPieceLen = 8;
+constexpr int kPieceRounds = 5;             // pieces per lane-slot
+constexpr int kPieceSlots = 64;             // lane-slots
+constexpr int kPieces = kPieceRounds * kPieceSlots;  // 320 >= number of real pieces (checked on host)
+
+struct LogmelTables {
+    float window[kNfft];          // periodic Hann
+    float2 tw1[7][128];           // W_1024^(n' * k1),  k1 = 1..7, n' = 0..127
+    float2 tw2[7][16];            // W_128^(n'' * k2),  k2 = 1..7, n'' = 0..15
+    float2 twp[512];              // W_2048^k, k = 0..511, except twp[0] = W_2048^512 (lane 0 takes bin 512)
+    int32_t piece_k0[kPieces];    // first bin of the piece
+    float piece_w[kPieces][kPieceLen];
+    int32_t filt_p0[kMels];       // first piece of filter f
+    int32_t filt_cnt[kMels];      // number of pieces of filter f
+};
+
+void build_mel_filterbank(float* out /*[80][1025]*/);
+void build_hann(double* out /*[2048]*/);
+int build_logmel_tables(LogmelTables* t);   // host; returns number of real pieces or <0
+const LogmelTables* device_tables();        // lazily uploaded for the current device (nullptr on error)
+
+// ---------------------------------------------------------------------------------------------
+// packed weight image (floats).  Offsets for n_conv = 2 | 3.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHidden = WW_HIDDEN;
+constexpr int kGateCols = 3 * kHidden;     // i, g, o (the forget gate is dead with zero state)
+
+struct PackedLayout {
+    int n_conv;
+    int c_last;        // 64 | 128
+    int64_t conv1_w;   // [32][9]
+    int64_t conv1_b;   // [32]
+    int64_t conv2_w;   // [2 ntile][144][64 lanes]  B-operand order
+    int64_t conv2_b;   // [64]
+    int64_t conv3_w;   // [4 ntile][288][64 lanes]  (n_conv 3)
+    int64_t conv3_b;   // [128]
+    int64_t l0_w;      // [c_last][768]  k-major, column = (hb*3 + gate)*32 + u
+    int64_t l0_b;      // [768]
+    int64_t l1_w;      // [256][768]
+    int64_t l1_b;      // [768]
+    int64_t fc_w;      // [2][256]
+    int64_t fc_b;      // [2] (+2 pad)
+    int64_t total;
+};
+PackedLayout packed_layout(int n_conv);
+
+// ---------------------------------------------------------------------------------------------
+// kernel launchers (defined in the .hip files)
+// ---------------------------------------------------------------------------------------------
+int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
+                  const int32_t* ring_pos /*nullable: streaming ring start per launch*/, int64_t ring_len,
+                  float* logmel, hipStream_t stream);
+int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
+                    float* pooled, hipStream_t stream);
+int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_conv, float* logits,
+                   float* prob /*nullable*/, hipStream_t stream);
+
+int require_gfx950();
+int device_cu_count();   // CUs of the current device (256 on MI355X); cached
+
+}  // namespace ww

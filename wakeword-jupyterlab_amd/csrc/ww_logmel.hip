@@ -1,0 +1,325 @@
+// K1: 16 kHz PCM -> log-mel dB [80][32] per clip, one persistent 4-wave workgroup per clip stream.
+//
+// Replaces normalize_audio + zero-pad + librosa.feature.melspectrogram + power_to_db(ref=np.max)
+// (/root/reference/wakeword_training_script.py:73-101).  Per clip:
+//
+//   32 frames of 2048 samples (hop 512, centred: 1024 zeros either side), one frame per WAVE at a time:
+//     z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1]                      (1024 complex points, 16 per lane)
+//     1024-point complex FFT = radix 8 x 8 x 16 in registers, two exchanges through the wave's
+//       private 8 KiB LDS slab (no workgroup barrier: LDS is in-order per wave)
+//     real-input split  X[k] = E[k] + W_2048^k O[k],  |X[k]|^2 and |X[1024-k]|^2 from the pair (Z[k], Z[1024-k])
+//   every 4 frames: sparse mel (2004 non-zeros as 8-bin pieces) over the 4 power spectra in LDS
+//   after 32 frames: per-clip max, 10 log10, clamp at -80 dB, coalesced store.
+//
+// Peak normalisation is deferred: the FFT is linear, so |X(x/p)|^2 = |X(x)|^2 / p^2 and the gain is
+// applied to the 2560 mel powers instead of the 16000 samples (the peak falls out of the frame loads).
+//
+// Algorithmic HBM bytes per clip: 64,000 read + 10,240 written = 74,240.
+#include "ww_internal.h"
+
+namespace ww {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWavesPerBlock * 64;
+// wave slab: 1024 complex = 2048 floats, +4 floats (keeps 16-byte alignment) so the 4 power rows of a
+// mel round start on different banks
+constexpr int kSlab = 2048 + 4;
+constexpr int kMelStride = kFrames + 1;
+// piece table copy in LDS: [kPieces][8] weights + [kPieces] first bins (ints), then filter -> piece ranges
+constexpr int kLdsFloats = kWavesPerBlock * kSlab + kPieces * kWavesPerBlock + kMels * kMelStride + 16 +
+                           kPieces * kPieceLen + kPieces + 2 * kMels;
+
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+// forward DFTs (e^{-2 pi i nk/N}), natural order in and out, all indices static -> registers
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_neg_i(a1 - a3);
+    a0 = t0 + t2; a2 = t0 - t2; a1 = t1 + t3; a3 = t1 - t3;
+}
+
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+    constexpr float c = 0.70710678118654752440f;
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+    o1 = make_float2(c * (o1.x + o1.y), c * (o1.y - o1.x));      // * W8^1 = (1 - i)/sqrt2
+    o2 = mul_neg_i(o2);                                           // * W8^2 = -i
+    o3 = make_float2(c * (o3.y - o3.x), -c * (o3.x + o3.y));      // * W8^3 = (-1 - i)/sqrt2
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    float2 e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    dft8(e);
+    dft8(o);
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;   // cos, sin(pi/8)
+    constexpr float c2 = 0.70710678118654752440f;
+    const float2 w[8] = {{1.f, 0.f}, {c1, -s1}, {c2, -c2}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-c2, -c2}, {-c1, -s1}};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 t = (k == 0) ? o[0] : (k == 4 ? mul_neg_i(o[4]) : cmul(o[k], w[k]));
+        v[k] = e[k] + t;
+        v[k + 8] = e[k] - t;
+    }
+}
+
+// 10*log10(x) as its own rounded product (no fma contraction with the following subtract), so that the
+// per-clip maximum maps to exactly 0 dB like librosa's `log_spec -= 10*log10(ref)`.
+__device__ __forceinline__ float db10(float x) {
+#pragma clang fp contract(off)
+    return 10.0f * log10f(x);
+}
+
+__device__ __forceinline__ void lds_order() {
+    // LDS traffic of one wave is in order; this only stops the compiler from moving accesses across phases.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float4 load_samples(const float* __restrict__ clip, int idx, int clip_len,
+                                               const int32_t* ring_pos_p, int ring_pos, int ring_len) {
+    // idx is a multiple of 4; [idx, idx+4) lies wholly before 0, wholly inside, or straddles clip_len
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx >= 0 && idx < clip_len) {
+        int at = idx;
+        if (ring_pos_p) { at = idx + ring_pos; if (at >= ring_len) at -= ring_len; }
+        if (idx + 4 <= clip_len) {
+            x = *reinterpret_cast<const float4*>(clip + at);
+        } else {
+            x.x = clip[at];
+            if (idx + 1 < clip_len) x.y = clip[at + 1];
+            if (idx + 2 < clip_len) x.z = clip[at + 2];
+        }
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
+                                                             int clip_len, int n_clips, int normalize,
+                                                             const int32_t* __restrict__ ring_pos_p, int ring_len,
+                                                             const LogmelTables* __restrict__ tb,
+                                                             float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* slabs = lds;                                         // [4][kSlab]
+    float* partial = slabs + kWavesPerBlock * kSlab;            // [kPieces][4]
+    float* mel = partial + kPieces * kWavesPerBlock;            // [80][33]
+    float* red = mel + kMels * kMelStride;                      // [16]
+    float* pw = red + 16;                                       // [kPieces][8]   (16-byte aligned)
+    int* pk0 = reinterpret_cast<int*>(pw + kPieces * kPieceLen);   // [kPieces]
+    int* fp0 = pk0 + kPieces;                                   // [80]
+    int* fcnt = fp0 + kMels;                                    // [80]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* slab = slabs + wave * kSlab;
+    float2* slab2 = reinterpret_cast<float2*>(slab);
+    float4* slab4 = reinterpret_cast<float4*>(slab);
+
+    // ---- lane constants, kept in registers across all frames of all clips ----
+    float4 t1[7];     // W_1024^{n' k1} for n' = 2*lane, 2*lane+1
+    float4 t2[7];     // W_128^{n'' k2} for n'' = 2*(lane&7), +1
+    float2 tp[8];     // W_2048^k for k = lane + 64 j (lane 0, j 0: k = 512)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        t1[k] = *reinterpret_cast<const float4*>(&tb->tw1[k][2 * lane]);
+        t2[k] = *reinterpret_cast<const float4*>(&tb->tw2[k][2 * (lane & 7)]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tp[j] = tb->twp[lane + 64 * j];
+
+    const int ring_pos = ring_pos_p ? *ring_pos_p : 0;
+
+    // sparse-mel tables live in LDS for the life of the workgroup (read every round by every thread)
+    for (int i = tid; i < kPieces * kPieceLen; i += kThreads) pw[i] = (&tb->piece_w[0][0])[i];
+    for (int i = tid; i < kPieces; i += kThreads) pk0[i] = tb->piece_k0[i];
+    if (tid < kMels) { fp0[tid] = tb->filt_p0[tid]; fcnt[tid] = tb->filt_cnt[tid]; }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+        const float* __restrict__ x = pcm + int64_t(clip) * clip_stride;
+        float peak = 0.f;
+
+#pragma unroll 1
+        for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
+            const int frame = round * kWavesPerBlock + wave;
+            const int base = frame * kHop - kNfft / 2 + 4 * lane;
+
+            // ---- load + window: lane holds z[128 n1 + 2 lane + q], q = 0,1, n1 = 0..7 ----
+            float2 za[8], zb[8];
+            int woff = 4 * lane;
+            asm volatile("" : "+v"(woff));   // keep the (L1-resident) window loads inside the loop: 32 fewer live VGPRs
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const float4 s = load_samples(x, base + 256 * n1, clip_len, ring_pos_p, ring_pos, ring_len);
+                const float4 w = *reinterpret_cast<const float4*>(&tb->window[256 * n1 + woff]);
+                peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
+                za[n1] = make_float2(s.x * w.x, s.y * w.y);
+                zb[n1] = make_float2(s.z * w.z, s.w * w.w);
+            }
+            // ---- pass 1: radix 8 over n1 (stride 128), twiddle W_1024^{n' k1}, store y[k1][n'] ----
+            dft8(za);
+            dft8(zb);
+            slab4[lane] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) {
+                const float2 a = cmul(za[k1], make_float2(t1[k1 - 1].x, t1[k1 - 1].y));
+                const float2 b = cmul(zb[k1], make_float2(t1[k1 - 1].z, t1[k1 - 1].w));
+                slab4[k1 * 64 + lane] = make_float4(a.x, a.y, b.x, b.y);     // float2 index k1*128 + 2*lane
+            }
+            lds_order();
+            // ---- pass 2: lane = (k1 = lane>>3, j = lane&7): radix 8 over n2 of y[k1][16 n2 + 2j + q] ----
+            {
+                const int k1 = lane >> 3, j = lane & 7;
+#pragma unroll
+                for (int n2 = 0; n2 < 8; ++n2) {
+                    const float4 v = slab4[k1 * 64 + n2 * 8 + j];
+                    za[n2] = make_float2(v.x, v.y);
+                    zb[n2] = make_float2(v.z, v.w);
+                }
+                lds_order();
+                dft8(za);
+                dft8(zb);
+                // u[k1][k2][n''] at float2 index k1*128 + k2*16 + n''
+                slab4[k1 * 64 + j] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
+#pragma unroll
+                for (int k2 = 1; k2 < 8; ++k2) {
+                    const float2 a = cmul(za[k2], make_float2(t2[k2 - 1].x, t2[k2 - 1].y));
+                    const float2 b = cmul(zb[k2], make_float2(t2[k2 - 1].z, t2[k2 - 1].w));
+                    slab4[k1 * 64 + k2 * 8 + j] = make_float4(a.x, a.y, b.x, b.y);
+                }
+            }
+            lds_order();
+            // ---- pass 3: lane = (k1, k2): radix 16 over n'' -> Z[k1 + 8 k2 + 64 k''] ----
+            {
+                float2 u[16];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const float4 v = slab4[lane * 8 + m];                    // float2 index lane*16 + 2m
+                    u[2 * m] = make_float2(v.x, v.y);
+                    u[2 * m + 1] = make_float2(v.z, v.w);
+                }
+                lds_order();
+                dft16(u);
+                const int lp = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) slab2[lp + 64 * kk] = u[kk];
+            }
+            lds_order();
+            // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
+            {
+                float2 a[8], b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = (j == 0 && lane == 0) ? 512 : lane + 64 * j;
+                    a[j] = slab2[k];
+                    b[j] = slab2[1024 - k];
+                }
+                lds_order();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = (j == 0 && lane == 0) ? 512 : lane + 64 * j;
+                    const float2 e = make_float2(0.5f * (a[j].x + b[j].x), 0.5f * (a[j].y - b[j].y));
+                    const float2 o = make_float2(0.5f * (a[j].y + b[j].y), 0.5f * (b[j].x - a[j].x));   // (a - conj b)/(2i)
+                    const float2 t = cmul(o, tp[j]);
+                    const float2 p = e + t, m = e - t;
+                    slab[k] = fmaf(p.x, p.x, p.y * p.y);
+                    slab[1024 - k] = fmaf(m.x, m.x, m.y * m.y);
+                }
+            }
+            __syncthreads();   // (A) the 4 power spectra of this round are complete
+
+            // ---- sparse mel over the round's 4 frames: thread = (frame-in-round, slot) ----
+            {
+                const int fr = tid & 3, slot = tid >> 2;
+                const float* srow = slabs + fr * kSlab;
+#pragma unroll
+                for (int c = 0; c < kPieceRounds; ++c) {
+                    const int p = c * kPieceSlots + slot;
+                    const int k0 = pk0[p];
+                    const float4 w0 = *reinterpret_cast<const float4*>(pw + p * kPieceLen);
+                    const float4 w1 = *reinterpret_cast<const float4*>(pw + p * kPieceLen + 4);
+                    const float* s = srow + k0;
+                    float acc = w0.x * s[0];
+                    acc = fmaf(w0.y, s[1], acc);
+                    acc = fmaf(w0.z, s[2], acc);
+                    acc = fmaf(w0.w, s[3], acc);
+                    acc = fmaf(w1.x, s[4], acc);
+                    acc = fmaf(w1.y, s[5], acc);
+                    acc = fmaf(w1.z, s[6], acc);
+                    acc = fmaf(w1.w, s[7], acc);
+                    partial[p * 4 + fr] = acc;
+                }
+            }
+            __syncthreads();   // (B) partials complete; slabs free for the next round's FFT
+            for (int idx = tid; idx < kMels * 4; idx += kThreads) {
+                const int f = idx >> 2, fr = idx & 3;
+                const int p0 = fp0[f], cnt = fcnt[f];
+                float acc = 0.f;
+                for (int q = 0; q < cnt; ++q) acc += partial[(p0 + q) * 4 + fr];
+                mel[f * kMelStride + round * 4 + fr] = acc;
+            }
+        }
+        __syncthreads();
+
+        // ---- per-clip peak and mel max ----
+        float mmax = 0.f;
+        for (int idx = tid; idx < kMels * kFrames; idx += kThreads)
+            mmax = fmaxf(mmax, mel[(idx >> 5) * kMelStride + (idx & 31)]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mmax = fmaxf(mmax, __shfl_xor(mmax, off));
+            peak = fmaxf(peak, __shfl_xor(peak, off));
+        }
+        if (lane == 0) { red[wave] = mmax; red[4 + wave] = peak; }
+        __syncthreads();
+        mmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        peak = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+
+        // power_to_db(S, ref=np.max, amin=1e-10, top_db=80): NaN must propagate (silent clip, 0/0)
+        const float amin = 1e-10f;
+        float g2 = 1.f;
+        if (normalize) { const float g = 1.0f / peak; g2 = g * g; }
+        float ref = mmax * g2;
+        ref = ref < amin ? amin : ref;
+        const float ref_db = db10(ref);
+        float* __restrict__ o = out + int64_t(clip) * (kMels * kFrames);
+        for (int idx = tid; idx < kMels * kFrames; idx += kThreads) {
+            float v = mel[(idx >> 5) * kMelStride + (idx & 31)] * g2;
+            v = v < amin ? amin : v;
+            float db = db10(v) - ref_db;
+            db = db < -80.0f ? -80.0f : db;
+            o[idx] = db;
+        }
+        __syncthreads();   // mel / red are rewritten by the next clip
+    }
+}
+
+int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
+                  const int32_t* ring_pos, int64_t ring_len, float* logmel, hipStream_t stream) {
+    if (n_clips == 0) return WW_OK;
+    const LogmelTables* tb = device_tables();
+    if (!tb) return WW_EHIP;
+    const int64_t resident = int64_t(device_cu_count()) * 3;      // LDS admits 3 workgroups per CU
+    const int grid = int(n_clips < resident ? n_clips : resident);
+    const size_t lds_bytes = sizeof(float) * kLdsFloats;
+    hipLaunchKernelGGL(logmel_kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
+                       int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+}  // namespace ww

@@ -1,0 +1,57 @@
+"""WakewordDataset drop-in (reference: /root/reference/wakeword_training_script.py:187-216, notebook cell 9).
+
+`dataset[idx]` returns `(FloatTensor [1, 80, 32], LongTensor [1])` exactly like the reference.  Because a
+GPU-backed `__getitem__` must not initialise HIP inside forked DataLoader workers, the per-item call is
+meant for `num_workers=0`; the fast path is `batches(batch_size)`, which decodes on the host and runs the
+log-mel kernel once per batch, yielding device tensors with `default_collate`'s shapes
+(`data [B,1,80,32]`, `target [B,1]`).
+
+One deliberate deviation: when a file fails to load the reference substitutes `np.zeros((80, 31))`
+(:210-211), whose width (31) differs from real items (32) and makes `default_collate` raise.  Here the
+substitute is zeros of the real width, [80, 32].
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .config import N_FRAMES
+
+
+class WakewordDataset(Dataset):
+    def __init__(self, wakeword_files, negative_files, processor, augment=False, verbose=True):
+        if augment:
+            raise NotImplementedError("augment=True (training-only augmentation) is outside the accelerated path")
+        self.wakeword_files = list(wakeword_files)
+        self.negative_files = list(negative_files)
+        self.processor = processor
+        self.augment = augment
+        self.files = self.wakeword_files + self.negative_files
+        self.labels = [1] * len(self.wakeword_files) + [0] * len(self.negative_files)
+        if verbose:
+            print(f"Dataset created with {len(self.files)} samples")
+            print(f"Wakeword samples: {len(self.wakeword_files)}")
+            print(f"Negative samples: {len(self.negative_files)}")
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, idx):
+        mel_spec = self.processor.process_audio_file(self.files[idx], augment=self.augment)
+        if mel_spec is None:
+            mel_spec = np.zeros((self.processor.config.N_MELS, N_FRAMES))
+        return torch.FloatTensor(np.asarray(mel_spec, dtype=np.float32)).unsqueeze(0), torch.LongTensor([self.labels[idx]])
+
+    def batches(self, batch_size=16):
+        """Yield (data [B,1,80,32] on the GPU, target [B,1] on the GPU) in file order."""
+        dev = self.processor._dev()
+        for s in range(0, len(self.files), batch_size):
+            paths = self.files[s:s + batch_size]
+            pcm, ok = self.processor.load_clips(paths)
+            # load_clips already peak-normalised each file before the crop/pad, as the reference does (:131-133)
+            data = self.processor.mel_batch(torch.from_numpy(pcm).to(dev), normalize=False)
+            if not ok.all():
+                data[torch.from_numpy(~ok).to(dev)] = 0.0
+            target = torch.tensor(self.labels[s:s + batch_size], dtype=torch.long, device=dev).unsqueeze(1)
+            yield data, target

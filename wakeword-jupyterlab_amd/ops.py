@@ -1,0 +1,238 @@
+"""Tensor-level entry points: torch custom ops (`torch.ops.wakeword_amd.*`) over the C ABI.
+
+PyTorch is plumbing here (device memory, the current HIP stream, op registration); the arithmetic is
+in libwakeword_amd.so.  Every op checks shape / dtype / device, launches on torch's current stream,
+never synchronises and never falls back to a CPU implementation.
+
+  logmel(pcm[B,n<=16000] f32, normalize)            -> [B,1,80,32]   (SURVEY.md boundary B1)
+  cnn_lstm_forward(x[B,1,80,T<=32], packed, n_conv) -> [B,2]         (boundary B2)
+  forward_pcm(pcm[B,n], packed, n_conv, normalize)  -> [B,2]         (boundary B3)
+  cnn_pool / lstm_fc                                 the two halves of B2, exposed for tests and profiling
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .config import CLIP_SAMPLES, N_FRAMES, AudioConfig
+
+N_MELS = AudioConfig.N_MELS
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _require_cuda_f32(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name} is on {t.device}: this path has no CPU implementation; move it to the MI355X (`.cuda()`)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+
+
+def c_last(n_conv: int) -> int:
+    return {2: 64, 3: 128}[n_conv]
+
+
+# ------------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------------
+def pack_state_dict(state_dict) -> np.ndarray:
+    """Reference state_dict (torch tensors or numpy arrays, torch layout) -> packed float32 image (host).
+
+    Accepts the key set of SimpleWakewordModel (train_wakeword.py:28-36) or WakewordModel
+    (wakeword_training_script.py:141-165); `lstm.weight_hh_l*` may be present and is ignored (it is
+    mathematically dead on this path)."""
+    def arr(key, shape):
+        if key not in state_dict:
+            raise KeyError(f"state_dict is missing '{key}'")
+        v = state_dict[key]
+        v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError(f"{key}: shape {tuple(v.shape)} != expected {tuple(shape)}")
+        return v
+
+    n_conv = 3 if "conv3.weight" in state_dict else 2
+    chans = [1, 32, 64, 128][: n_conv + 1]
+    keep = []
+    sd = nat.StateDict()
+    sd.n_conv, sd.hidden = n_conv, 256
+    for i in range(n_conv):
+        w = arr(f"conv{i + 1}.weight", (chans[i + 1], chans[i], 3, 3)); b = arr(f"conv{i + 1}.bias", (chans[i + 1],))
+        keep += [w, b]
+        sd.conv_weight[i], sd.conv_bias[i] = w.ctypes.data, b.ctypes.data
+    for layer, nin in enumerate([chans[-1], 256]):
+        w = arr(f"lstm.weight_ih_l{layer}", (1024, nin))
+        bi = arr(f"lstm.bias_ih_l{layer}", (1024,)); bh = arr(f"lstm.bias_hh_l{layer}", (1024,))
+        keep += [w, bi, bh]
+        sd.lstm_weight_ih[layer], sd.lstm_bias_ih[layer], sd.lstm_bias_hh[layer] = w.ctypes.data, bi.ctypes.data, bh.ctypes.data
+    fw = arr("fc.weight", (2, 256)); fb = arr("fc.bias", (2,))
+    keep += [fw, fb]
+    sd.fc_weight, sd.fc_bias = fw.ctypes.data, fb.ctypes.data
+    out = np.empty(nat.check(nat.lib.ww_packed_weights_floats(n_conv)), dtype=np.float32)
+    nat.check(nat.lib.ww_pack_weights_host(C.byref(sd), out.ctypes.data))
+    return out
+
+
+def n_conv_of_packed(packed: torch.Tensor) -> int:
+    for n_conv in (2, 3):
+        if packed.numel() == nat.lib.ww_packed_weights_floats(n_conv):
+            return n_conv
+    raise ValueError(f"packed weight image of {packed.numel()} floats matches neither model")
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches (plain functions; the registered custom ops below wrap them)
+# ------------------------------------------------------------------------------------------------
+def _check_pcm(pcm: torch.Tensor) -> torch.Tensor:
+    _require_cuda_f32(pcm, "pcm")
+    if pcm.dim() != 2:
+        raise ValueError(f"pcm: expected [B, samples], got {tuple(pcm.shape)}")
+    if pcm.shape[1] == 0 or pcm.shape[1] > CLIP_SAMPLES:
+        raise ValueError(f"pcm: {pcm.shape[1]} samples per clip; the front-end takes 1..{CLIP_SAMPLES} "
+                         "(crop longer clips on the host, pad_or_truncate wakeword_training_script.py:78-83)")
+    if pcm.stride(1) != 1 or (pcm.shape[0] > 1 and pcm.stride(0) % 4) or pcm.data_ptr() % 16:
+        pcm = pcm.contiguous()
+        if pcm.shape[1] % 4 and pcm.shape[0] > 1:      # row stride must be a multiple of 4 floats
+            pad = torch.zeros(pcm.shape[0], (pcm.shape[1] + 3) // 4 * 4, device=pcm.device, dtype=pcm.dtype)
+            pad[:, : pcm.shape[1]] = pcm
+            pcm = pad[:, : pcm.shape[1]]
+    return pcm
+
+
+def _logmel_impl(pcm: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    pcm = _check_pcm(pcm)
+    B, n = pcm.shape
+    out = torch.empty((B, 1, N_MELS, N_FRAMES), device=pcm.device, dtype=torch.float32)
+    with torch.cuda.device(pcm.device):
+        nat.check(nat.lib.ww_logmel_f32(_ptr(pcm), B, pcm.stride(0) if B > 1 else n, n, int(bool(normalize)), _ptr(out), _stream()))
+    return out
+
+
+def _check_x(x: torch.Tensor) -> torch.Tensor:
+    _require_cuda_f32(x, "x")
+    if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != N_MELS:
+        raise ValueError(f"x: expected [B, 1, {N_MELS}, T], got {tuple(x.shape)}")
+    if not 1 <= x.shape[3] <= 32:
+        raise NotImplementedError(f"x: T = {x.shape[3]} frames; the conv kernels are built for 1..32 (1 s clips give 32)")
+    return x.contiguous()
+
+
+def _check_packed(packed: torch.Tensor, n_conv: int, like: torch.Tensor) -> None:
+    _require_cuda_f32(packed, "packed weights")
+    if packed.device != like.device:
+        raise RuntimeError(f"packed weights on {packed.device}, input on {like.device}")
+    if n_conv not in (2, 3) or packed.numel() != nat.lib.ww_packed_weights_floats(n_conv) or not packed.is_contiguous():
+        raise ValueError("packed weights do not match n_conv (use ops.pack_state_dict)")
+
+
+def _cnn_pool_impl(x: torch.Tensor, packed: torch.Tensor, n_conv: int) -> torch.Tensor:
+    x = _check_x(x)
+    _check_packed(packed, n_conv, x)
+    B, T = x.shape[0], x.shape[3]
+    pooled = torch.empty((B, c_last(n_conv)), device=x.device, dtype=torch.float32)
+    nbytes = nat.check(nat.lib.ww_cnn_scratch_bytes(B, n_conv))
+    scratch = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib.ww_cnn_pool_f32(_ptr(x), B, T, _ptr(packed), n_conv, _ptr(scratch) if nbytes else None, _ptr(pooled), _stream()))
+    return pooled
+
+
+def _lstm_fc_impl(pooled: torch.Tensor, packed: torch.Tensor, n_conv: int) -> torch.Tensor:
+    _require_cuda_f32(pooled, "pooled")
+    _check_packed(packed, n_conv, pooled)
+    if pooled.dim() != 2 or pooled.shape[1] != c_last(n_conv):
+        raise ValueError(f"pooled: expected [B, {c_last(n_conv)}], got {tuple(pooled.shape)}")
+    pooled = pooled.contiguous()
+    logits = torch.empty((pooled.shape[0], 2), device=pooled.device, dtype=torch.float32)
+    with torch.cuda.device(pooled.device):
+        nat.check(nat.lib.ww_lstm_fc_f32(_ptr(pooled), pooled.shape[0], _ptr(packed), n_conv, _ptr(logits), _stream()))
+    return logits
+
+
+def _workspace(n: int, n_conv: int, device) -> torch.Tensor:
+    return torch.empty(max(1, nat.check(nat.lib.ww_workspace_bytes(n, n_conv))), device=device, dtype=torch.uint8)
+
+
+def _cnn_lstm_forward_impl(x: torch.Tensor, packed: torch.Tensor, n_conv: int) -> torch.Tensor:
+    x = _check_x(x)
+    _check_packed(packed, n_conv, x)
+    B, T = x.shape[0], x.shape[3]
+    logits = torch.empty((B, 2), device=x.device, dtype=torch.float32)
+    ws = _workspace(B, n_conv, x.device)
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib.ww_model_forward_f32(_ptr(x), B, T, _ptr(packed), n_conv, _ptr(ws), _ptr(logits), _stream()))
+    return logits
+
+
+def _forward_pcm_impl(pcm: torch.Tensor, packed: torch.Tensor, n_conv: int, normalize: bool = True) -> torch.Tensor:
+    pcm = _check_pcm(pcm)
+    _check_packed(packed, n_conv, pcm)
+    B, n = pcm.shape
+    logits = torch.empty((B, 2), device=pcm.device, dtype=torch.float32)
+    ws = _workspace(B, n_conv, pcm.device)
+    with torch.cuda.device(pcm.device):
+        nat.check(nat.lib.ww_forward_pcm_f32(_ptr(pcm), B, pcm.stride(0) if B > 1 else n, n, int(bool(normalize)),
+                                             _ptr(packed), n_conv, _ptr(ws), _ptr(logits), _stream()))
+    return logits
+
+
+# ------------------------------------------------------------------------------------------------
+# torch custom ops: torch.ops.wakeword_amd.{logmel,cnn_pool,lstm_fc,cnn_lstm_forward,forward_pcm}
+# ------------------------------------------------------------------------------------------------
+_lib = torch.library.Library("wakeword_amd", "DEF")
+_lib.define("logmel(Tensor pcm, bool normalize=True) -> Tensor")
+_lib.define("cnn_pool(Tensor x, Tensor packed, int n_conv) -> Tensor")
+_lib.define("lstm_fc(Tensor pooled, Tensor packed, int n_conv) -> Tensor")
+_lib.define("cnn_lstm_forward(Tensor x, Tensor packed, int n_conv) -> Tensor")
+_lib.define("forward_pcm(Tensor pcm, Tensor packed, int n_conv, bool normalize=True) -> Tensor")
+_lib.impl("logmel", _logmel_impl, "CUDA")
+_lib.impl("cnn_pool", _cnn_pool_impl, "CUDA")
+_lib.impl("lstm_fc", _lstm_fc_impl, "CUDA")
+_lib.impl("cnn_lstm_forward", _cnn_lstm_forward_impl, "CUDA")
+_lib.impl("forward_pcm", _forward_pcm_impl, "CUDA")
+
+
+def _no_cpu(name):
+    def impl(*args, **kwargs):
+        raise RuntimeError(f"wakeword_amd::{name}: no CPU implementation exists (HIP/gfx950 only); move the tensors to the GPU")
+    return impl
+
+
+for _n in ("logmel", "cnn_pool", "lstm_fc", "cnn_lstm_forward", "forward_pcm"):
+    _lib.impl(_n, _no_cpu(_n), "CPU")
+
+
+def logmel(pcm: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    return torch.ops.wakeword_amd.logmel(pcm, normalize)
+
+
+def cnn_pool(x, packed, n_conv):
+    return torch.ops.wakeword_amd.cnn_pool(x, packed, n_conv)
+
+
+def lstm_fc(pooled, packed, n_conv):
+    return torch.ops.wakeword_amd.lstm_fc(pooled, packed, n_conv)
+
+
+def cnn_lstm_forward(x, packed, n_conv):
+    return torch.ops.wakeword_amd.cnn_lstm_forward(x, packed, n_conv)
+
+
+def forward_pcm(pcm, packed, n_conv, normalize: bool = True):
+    return torch.ops.wakeword_amd.forward_pcm(pcm, packed, n_conv, normalize)
+
+
+def init() -> None:
+    """Upload the front-end tables for the current device (needed before hipGraph capture)."""
+    nat.check(nat.lib.ww_init())
