@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1 s / 16 kHz clips per second, PCM in HBM -> logits in HBM (mel + CNN + LSTM).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 4096] [--arch simple]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+one rank per GPU; the batch is sharded by clip (4096 clips PER GPU, weak scaling), every rank runs
+K1 (log-mel) -> K2 (conv stack + pool) -> K3 (LSTM + fc) on its shard and the per-clip logits are
+all-gathered over RCCL so that every rank holds all N x 4096 x 2 logits.
+
+A "step" = one pass of the whole path over one batch that is already resident in HBM.  K steps are
+timed between barrier + torch.cuda.synchronize() on both sides; the slowest rank's time is used.
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline      the dominant kernel (K2, f32 MFMA): algorithmic flops / its average launch duration
+                (HIP events on the launch stream inside the timed region) / the dense f32 MFMA peak
+  stages        the same for K1 (HBM roofline, 74,240 algorithmic bytes per clip) and K3 (gate GEMMs)
+  cpu_baseline  the CPU oracle (numpy log-mel per clip + torch CPU Conv2d/LSTM/Linear) timed on this
+                host on a bounded sample of the same clips (rank 0, N = 1 only)
+  parity        max |err| of the measured path against that oracle on the sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per clip, SURVEY.md section 8(d) (T = 32 frames)
+K1_BYTES_PER_CLIP = 16000 * 4 + 80 * 32 * 4            # 74,240: PCM read once + log-mel written once
+K1_FLOPS_PER_CLIP = 2.1e6                              # 32 x 2.5 N log2 N real FFTs + window/power/sparse mel/log
+K2_FLOPS_PER_CLIP = {"simple": 1_474_560 + 94_371_840, "full": 1_474_560 + 94_371_840 + 377_487_360}
+K3_FLOPS_PER_CLIP = {"simple": 98_304 + 393_216 + 1_024, "full": 196_608 + 393_216 + 1_024}   # live gates i,g,o only
+HBM_PEAK = 8.0e12                                      # B/s, MI355X_MICROARCH.md chip table (spec)
+MFMA_F32_PEAK = 157.3e12                               # flop/s, dense f32 MFMA = f32 vector peak (same table)
+METRIC = "1s/16kHz clips/sec end-to-end (mel+CNN+LSTM)"
+
+
+def cpu_baseline(clips, sd, budget_s=20.0):
+    """The reference path restated on the CPU (oracle/): per-clip numpy log-mel, then torch CPU layers."""
+    from oracle import mel_oracle, model_oracle
+    basis = mel_oracle.mel_filterbank()
+    module = model_oracle.torch_module_from_state_dict(sd)
+    mel_oracle.process_clip(clips[0], True, basis)                       # warm caches / FFT plans
+    t0 = time.perf_counter()
+    n, mels = 0, []
+    while n < len(clips) and (time.perf_counter() - t0 < budget_s * 0.6 or n < 16):
+        mels.append(mel_oracle.process_clip(clips[n], True, basis))
+        n += 1
+    t_mel = time.perf_counter() - t0
+    x = torch.from_numpy(np.stack(mels)[:, None].astype(np.float32))
+    with torch.no_grad():
+        module(x[:2])
+        t1 = time.perf_counter()
+        logits = module(x).numpy()
+        t_model = time.perf_counter() - t1
+    total = t_mel + t_model
+    return {
+        "value": n / total, "unit": "clips/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        "sample": f"{n} of the bench clips, one at a time: numpy/scipy float64-FFT log-mel (1 thread) then torch CPU "
+                  f"Conv2d/LSTM/Linear forward in one batch ({torch.get_num_threads()} threads)",
+        "mel_clips_per_s": n / t_mel, "model_clips_per_s": n / t_model, "host_cpus": os.cpu_count(),
+    }, np.stack(mels)[:, None].astype(np.float32), logits
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="clips per GPU per step")
+    ap.add_argument("--arch", default="simple", choices=["simple", "full"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import wakeword_jupyterlab_amd as pkg
+    from wakeword_jupyterlab_amd import distributed as wdist
+
+    rank, world, local = wdist.init_from_env("nccl")
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only implementation of this path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    from wakeword_jupyterlab_amd import _native as nat
+    from wakeword_jupyterlab_amd import ops
+
+    ops.init()
+    B = args.batch
+    n_conv = 2 if args.arch == "simple" else 3
+    sd = pkg.synth.make_state_dict(args.arch, seed=1234)
+    model = (pkg.SimpleWakewordModel() if args.arch == "simple" else pkg.WakewordModel())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    packed = model.packed_weights()
+
+    # rank r holds clips [r*B, (r+1)*B) of the global batch; built from 256 distinct synthetic clips per rank
+    host = pkg.synth.make_clips_tiled(rank * B, B, unique=256)
+    pcm = torch.from_numpy(host).to(dev)
+    ws = torch.empty(nat.check(nat.lib.ww_workspace_bytes(B, n_conv)), device=dev, dtype=torch.uint8)
+    mel = torch.empty((B, 1, 80, 32), device=dev)
+    pooled = torch.empty((B, ops.c_last(n_conv)), device=dev)
+    scratch_bytes = nat.check(nat.lib.ww_cnn_scratch_bytes(B, n_conv))
+    scratch = torch.empty(max(1, scratch_bytes), device=dev, dtype=torch.uint8)
+    logits = torch.empty((B, 2), device=dev)
+    gathered = torch.empty((world * B, 2), device=dev) if world > 1 else logits
+
+    import ctypes as C
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    stream = torch.cuda.current_stream()
+    st = C.c_void_p(stream.cuda_stream)
+
+    def step(ev=None):
+        if ev: ev[0].record(stream)
+        nat.check(nat.lib.ww_logmel_f32(p(pcm), B, 16000, 16000, 1, p(mel), st))
+        if ev: ev[1].record(stream)
+        nat.check(nat.lib.ww_cnn_pool_f32(p(mel), B, 32, p(packed), n_conv, p(scratch) if scratch_bytes else None, p(pooled), st))
+        if ev: ev[2].record(stream)
+        nat.check(nat.lib.ww_lstm_fc_f32(p(pooled), B, p(packed), n_conv, p(logits), st))
+        if ev: ev[3].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, logits)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events])    # [steps, 3] K1,K2,K3
+    k1_ms, k2_ms, k3_ms = [float(v) for v in ms.mean(axis=0)]
+
+    if rank == 0:
+        clips_per_s = world * B * args.steps / elapsed
+        k2_flops = K2_FLOPS_PER_CLIP[args.arch] * B
+        k2_ach = k2_flops / (k2_ms * 1e-3)
+        out = {
+            "metric": METRIC, "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[2]: batch={B} 1 s/16 kHz clips per GPU, full log-mel + CNN + LSTM HIP forward "
+                            f"(K1 -> K2 -> K3{' -> RCCL all-gather of logits' if world > 1 else ''}), PCM and logits resident in HBM",
+                "model": "SimpleWakewordModel (train_wakeword.py:28-49), random-init weights seed 1234" if args.arch == "simple"
+                         else "WakewordModel 3-conv (wakeword_training_script.py:141-184), random-init weights seed 1234",
+                "global_batch": world * B, "clips_per_gpu": B,
+                "parallelism": f"clips sharded over {world} GPU(s), replicated weights",
+            },
+            "roofline": {
+                "kernel": "cnn2_kernel<POOL> (conv1 + conv2 + ReLU + avg-pool, v_mfma_f32_32x32x2_f32)" if args.arch == "simple"
+                          else "cnn2_kernel + cnn3_kernel (conv stack, v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "achieved": k2_ach / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": k2_ach / MFMA_F32_PEAK, "traffic": None,
+                "flops_per_launch": k2_flops, "avg_launch_ms": k2_ms,
+            },
+            "stages": {
+                "K1_logmel": {"avg_ms": k1_ms, "bound": "hbm", "achieved_GBps": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / 1e9,
+                              "peak_GBps": HBM_PEAK / 1e9, "frac": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / HBM_PEAK,
+                              "clips_per_s": B / (k1_ms * 1e-3),
+                              "f32_vector_frac": K1_FLOPS_PER_CLIP * B / (k1_ms * 1e-3) / MFMA_F32_PEAK},
+                "K2_cnn": {"avg_ms": k2_ms, "clips_per_s": B / (k2_ms * 1e-3)},
+                "K3_lstm_fc": {"avg_ms": k3_ms, "bound": "mfma", "achieved_TFLOPs": K3_FLOPS_PER_CLIP[args.arch] * B / (k3_ms * 1e-3) / 1e12,
+                               "mfma_f32_frac": K3_FLOPS_PER_CLIP[args.arch] * B / (k3_ms * 1e-3) / MFMA_F32_PEAK},
+                "kernel_ms_sum": k1_ms + k2_ms + k3_ms,
+            },
+            "device": nat.device_info(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_sample = 256
+            base, ref_mel, ref_logits = cpu_baseline(host[:n_sample], sd)
+            n = len(ref_mel)
+            with torch.no_grad():
+                got_mel = ops.logmel(pcm[:n], True).cpu().numpy()
+                got_logits = model.forward_pcm(pcm[:n]).cpu().numpy()
+            out["cpu_baseline"] = base
+            out["parity"] = {"clips": n, "logmel_max_abs_err_dB": float(np.abs(got_mel - ref_mel).max()),
+                             "logits_max_abs_err": float(np.abs(got_logits - ref_logits).max()),
+                             "against": "oracle/ (librosa is not installed: mel parity vs librosa itself is unpinned)"}
+            out["gpu_over_cpu"] = clips_per_s / base["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""world_size-2 rehearsal of the multi-GPU path on CPU (gloo): sharding + the one collective (logits all-gather).
+
+The model itself has no CPU implementation, so each rank fabricates its shard's logits with the oracle; what is
+under test is the N > 1 plumbing bench.py and sharded_forward_pcm use: init_from_env, shard_bounds,
+all_gather_logits (equal and ragged shards), rank-order of the result.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from wakeword_jupyterlab_amd import distributed as wd
+
+    r, w, _ = wd.init_from_env("gloo")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    lo, hi = wd.shard_bounds(n_total, rank, world)
+    # "logits" of clip i are (i, -i): any misplacement shows up in the gathered tensor
+    local = torch.stack([torch.arange(lo, hi, dtype=torch.float32), -torch.arange(lo, hi, dtype=torch.float32)], 1)
+    full = wd.all_gather_logits(local, n_total)
+    full_nohint = wd.all_gather_logits(local)              # without n_total: padded to the largest shard
+    q.put((rank, lo, hi, full.numpy(), full_nohint.shape[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7, 1])
+def test_two_rank_all_gather_of_logits(n_total):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([np.arange(n_total, dtype=np.float32), -np.arange(n_total, dtype=np.float32)], 1)
+    covered = []
+    for rank, lo, hi, full, n_nohint in results:
+        assert np.array_equal(full, want)                  # every rank holds every clip's logits, in clip order
+        assert n_nohint == world * ((n_total + world - 1) // world)
+        covered += list(range(lo, hi))
+    assert sorted(covered) == list(range(n_total))         # shards partition the batch
+
+
+def test_shard_bounds_partition_any_batch():
+    from wakeword_jupyterlab_amd.distributed import shard_bounds
+    for n in (0, 1, 5, 4096, 32768, 32769):
+        for world in (1, 2, 4, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) == (n + world - 1) // world
+    assert [shard_bounds(32768, r, 8) for r in (0, 7)] == [(0, 4096), (28672, 32768)]   # BASELINE configs[3]
+
+
+def test_single_process_is_a_no_op():
+    from wakeword_jupyterlab_amd.distributed import all_gather_logits, init_from_env
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert init_from_env("gloo") == (0, 1, 0)
+    x = torch.randn(5, 2)
+    assert all_gather_logits(x) is x

@@ -1,0 +1,137 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU compute)."""
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import wakeword_jupyterlab_amd as pkg
+from oracle import model_oracle
+from wakeword_jupyterlab_amd.audio import AudioProcessor, _read_wav
+from wakeword_jupyterlab_amd.config import AudioConfig, check_audio_config
+from wakeword_jupyterlab_amd.dataset import WakewordDataset
+
+
+def _write_wav(path, x, sr=16000, bits=16, channels=1, fmt=1):
+    x = np.asarray(x, dtype=np.float64).reshape(-1, channels)
+    if fmt == 3:
+        raw = x.astype("<f4").tobytes(); bits = 32
+    elif bits == 16:
+        raw = np.clip(np.round(x * 32767), -32768, 32767).astype("<i2").tobytes()
+    elif bits == 8:
+        raw = np.clip(np.round(x * 127 + 128), 0, 255).astype(np.uint8).tobytes()
+    else:
+        raise ValueError
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, fmt, channels, sr, sr * channels * bits // 8, channels * bits // 8, bits) + b"data" + struct.pack("<I", len(raw))
+    with open(path, "wb") as f:
+        f.write(hdr + raw)
+
+
+def test_state_dict_keys_and_shapes_match_the_reference_models():
+    simple, full = pkg.SimpleWakewordModel(), pkg.WakewordModel()
+    ref_s = model_oracle.make_torch_module("simple").state_dict()
+    ref_f = model_oracle.make_torch_module("full").state_dict()
+    assert {k: tuple(v.shape) for k, v in simple.state_dict().items()} == {k: tuple(v.shape) for k, v in ref_s.items()}
+    assert {k: tuple(v.shape) for k, v in full.state_dict().items()} == {k: tuple(v.shape) for k, v in ref_f.items()}
+    assert sum(p.numel() for p in simple.parameters()) == 875394
+    assert sum(p.numel() for p in full.parameters()) == 1014786           # model_architecture.txt:10
+    assert full.mel_width == 32 and full.cnn_output_size == 128 and full.mel_height == 80
+    # reference checkpoints load: {'model_state_dict': ...} with every key, weight_hh included
+    sd = pkg.synth.make_state_dict("full", seed=3)
+    full.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert torch.equal(full.lstm.weight_hh_l1, torch.from_numpy(sd["lstm.weight_hh_l1"]))
+
+
+def test_checkpoint_round_trip(tmp_path):
+    from wakeword_jupyterlab_amd.model import load_checkpoint
+    m = pkg.SimpleWakewordModel()
+    path = os.path.join(tmp_path, "best_wakeword_model.pth")
+    torch.save({"epoch": 41, "model_state_dict": m.state_dict(), "val_acc": 98.93}, path)   # layout of script :327-335
+    m2 = pkg.SimpleWakewordModel()
+    ckpt = load_checkpoint(m2, path, map_location="cpu")
+    assert ckpt["epoch"] == 41
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_unsupported_configurations_are_refused():
+    class Cfg(AudioConfig):
+        N_FFT = 1024
+    with pytest.raises(NotImplementedError):
+        check_audio_config(Cfg)
+    with pytest.raises(NotImplementedError):
+        AudioProcessor(Cfg)
+    class MC(pkg.ModelConfig):
+        HIDDEN_SIZE = 128
+    with pytest.raises(NotImplementedError):
+        pkg.WakewordModel(config=MC)
+    with pytest.raises(NotImplementedError):
+        AudioProcessor().augment_audio(np.zeros(16000))
+
+
+def test_wav_reader_and_load_audio(tmp_path):
+    x = pkg.synth.make_clip(3) * 0.5
+    p16 = os.path.join(tmp_path, "a.wav"); _write_wav(p16, x)
+    pf = os.path.join(tmp_path, "f.wav"); _write_wav(pf, x, fmt=3)
+    p8 = os.path.join(tmp_path, "u8.wav"); _write_wav(p8, x, bits=8)
+    pst = os.path.join(tmp_path, "st.wav"); _write_wav(pst, np.stack([x, -x * 0.5], 1), channels=2)
+    p8k = os.path.join(tmp_path, "8k.wav"); _write_wav(p8k, x[::2], sr=8000)
+    proc = AudioProcessor()
+    a = proc.load_audio(p16)
+    assert a.dtype == np.float32 and a.shape == (16000,) and np.abs(a - x).max() < 1 / 32768 + 1e-7
+    assert np.array_equal(proc.load_audio(pf), x.astype(np.float32))
+    assert np.abs(proc.load_audio(p8) - x).max() < 1 / 64
+    assert np.abs(proc.load_audio(pst) - 0.25 * x).max() < 1e-4              # mono = channel mean, as librosa.load
+    r = proc.load_audio(p8k)
+    assert r.shape == (16000,) and r.dtype == np.float32                     # resampled 8 k -> 16 k
+    data, sr = _read_wav(pst)
+    assert data.shape == (16000, 2) and sr == 16000
+    # failure: print + None, never raise (reference :66-71)
+    bad = os.path.join(tmp_path, "bad.wav"); open(bad, "wb").write(b"not a wav")
+    assert proc.load_audio(bad) is None and proc.load_audio(os.path.join(tmp_path, "missing.wav")) is None
+    assert proc.process_audio_file(bad) is None
+
+
+def test_normalize_and_pad_or_truncate_follow_the_reference():
+    proc = AudioProcessor()
+    x = np.array([0.5, -2.0, 1.0], np.float32)
+    assert np.array_equal(proc.normalize_audio(x), x / 2.0)
+    assert proc.normalize_audio(np.zeros(0)).size == 0
+    assert np.isnan(proc.normalize_audio(np.zeros(4, np.float32))).all()          # 0/0, like the reference
+    assert np.array_equal(proc.pad_or_truncate(x, 5), np.array([0.5, -2.0, 1.0, 0, 0], np.float32))
+    long = np.arange(20000, dtype=np.float32)
+    random.seed(12); start = random.randint(0, 4000); random.seed(12)
+    assert np.array_equal(proc.pad_or_truncate(long, 16000), long[start:start + 16000])
+    assert proc.audio_to_mel(np.zeros(0)).shape == (80, 32)                       # empty clip: zeros, no GPU needed
+
+
+def test_dataset_bookkeeping_and_load_clips(tmp_path, capsys):
+    files = []
+    for i in range(3):
+        p = os.path.join(tmp_path, f"w{i}.wav"); _write_wav(p, pkg.synth.make_clip(i)[: 9000 + 3000 * i] * 0.3); files.append(p)
+    bad = os.path.join(tmp_path, "broken.wav"); open(bad, "wb").write(b"RIFFxxxx")
+    ds = WakewordDataset(files[:2], [files[2], bad], AudioProcessor())
+    assert "Dataset created with 4 samples" in capsys.readouterr().out
+    assert len(ds) == 4 and ds.labels == [1, 1, 0, 0] and ds.files[-1] == bad
+    pcm, ok = ds.processor.load_clips(ds.files)
+    assert pcm.shape == (4, 16000) and list(ok) == [True, True, True, False]
+    assert abs(np.abs(pcm[0]).max() - 1.0) < 1e-6 and not pcm[0, 9000:].any()      # peak-normalised, right zero-padded
+    assert not pcm[3].any()
+    with pytest.raises(NotImplementedError):
+        WakewordDataset(files, [], AudioProcessor(), augment=True)
+
+
+def test_synth_is_deterministic_and_follows_the_recipe():
+    a, b = pkg.synth.make_clip(0), pkg.synth.make_clip(0)
+    assert np.array_equal(a, b) and a.dtype == np.float32 and a.shape == (16000,)
+    assert not np.array_equal(pkg.synth.make_clip(1), pkg.synth.make_clip(2))
+    # clip 0 = the reference's wakeword recipe (200 Hz + 400 Hz + 0.1 noise): spectrum peaks at 200 Hz
+    spec = np.abs(np.fft.rfft(a.astype(np.float64)))
+    assert spec.argmax() == 200 and spec[400] > 0.5 * spec[200]
+    assert 0.17 < pkg.synth.make_clip(1).std() < 0.23                                # negatives: 0.2 * randn
+    n = pkg.synth.normal(9, 200000)
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01
+    t = pkg.synth.make_clips_tiled(0, 40, unique=16)
+    assert t.shape == (40, 16000) and np.array_equal(t[:16], pkg.synth.make_clips(0, 16)) and not np.array_equal(t[16], t[0])

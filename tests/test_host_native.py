@@ -1,0 +1,132 @@
+"""CPU-only checks of the native library's host side: it loads, exports exactly what include/wakeword_amd.h
+declares, builds the front-end tables and the packed weight image correctly, and refuses to compute without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import wakeword_jupyterlab_amd as pkg
+from oracle import mel_oracle
+from wakeword_jupyterlab_amd import _native as nat
+from wakeword_jupyterlab_amd import ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.is_available()
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "wakeword_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"WW_API\s+[\w\s\*]+?\b(ww_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol_and_binding_covers_them():
+    names = _header_functions()
+    assert len(names) >= 19 and "ww_logmel_f32" in names and "ww_streamer_step" in names
+    lib = C.CDLL(nat.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(nat.PROTOTYPES) == names                 # ctypes table == header, nothing more, nothing less
+    assert nat.lib.ww_abi_version() == 1
+    # nothing else leaks out of the shared object
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", nat.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert [e for e in exported if e.startswith("ww_")] == names
+
+
+def test_mel_filterbank_and_window_match_the_oracle_bit_for_bit():
+    M = np.empty((80, 1025), np.float32)
+    nat.check(nat.lib.ww_mel_filterbank_host(M.ctypes.data))
+    ref = mel_oracle.mel_filterbank()
+    assert (M != 0).sum() == 2004
+    assert np.array_equal(M != 0, ref != 0)
+    assert np.abs(M - ref).max() <= 2e-9 and np.abs(M / np.where(ref == 0, 1, ref) - (ref != 0)).max() <= 1.2e-7   # <= 1 ulp
+    w = np.empty(2048, np.float32)
+    nat.check(nat.lib.ww_hann_window_host(w.ctypes.data))
+    assert np.abs(w.astype(np.float64) - mel_oracle.hann_window()).max() <= 6e-8 and w[0] == 0.0 and w[1024] == 1.0
+
+
+@pytest.mark.parametrize("arch", ["simple", "full"])
+def test_packed_weight_image_layout(arch):
+    sd = pkg.synth.make_state_dict(arch, seed=5)
+    n_conv = 2 if arch == "simple" else 3
+    p = ops.pack_state_dict(sd)
+    assert p.dtype == np.float32 and p.size == nat.lib.ww_packed_weights_floats(n_conv)
+    o = 0
+    def take(n):
+        nonlocal o
+        v = p[o:o + n]; o += (n + 3) // 4 * 4
+        return v
+    assert np.array_equal(take(288), sd["conv1.weight"].reshape(-1))
+    assert np.array_equal(take(32), sd["conv1.bias"])
+    # conv B operand: [ntile][(c*3+dy)*3+dx][lane] = W[32*nt + lane%32][2c + lane//32][dy][dx]
+    for li, cin, cout in [(2, 32, 64), (3, 64, 128)][: n_conv - 1]:
+        wb = take(cout // 32 * (cin // 2 * 9) * 64).reshape(cout // 32, cin // 2, 3, 3, 2, 32)
+        w = sd[f"conv{li}.weight"]                                    # [cout][cin][3][3]
+        want = w.reshape(cout // 32, 32, cin // 2, 2, 3, 3).transpose(0, 2, 4, 5, 3, 1)
+        assert np.array_equal(wb, want)
+        assert np.array_equal(take(cout), sd[f"conv{li}.bias"])
+    # LSTM: [K][768], column (hb*3 + g)*32 + u <- row goff[g] + 32*hb + u, gates (i, g, o) = rows 0, 512, 768
+    for layer, K in enumerate([64 if arch == "simple" else 128, 256]):
+        wt = take(K * 768).reshape(K, 8, 3, 32)
+        b = take(768).reshape(8, 3, 32)
+        w_ih = sd[f"lstm.weight_ih_l{layer}"]
+        bias = sd[f"lstm.bias_ih_l{layer}"] + sd[f"lstm.bias_hh_l{layer}"]
+        for g, off in enumerate([0, 512, 768]):
+            rows = (off + 32 * np.arange(8)[:, None] + np.arange(32)[None]).reshape(-1)
+            assert np.array_equal(wt[:, :, g, :].reshape(K, 256), w_ih[rows].T)
+            assert np.array_equal(b[:, g, :].reshape(-1), bias[rows])
+    assert np.array_equal(take(512), sd["fc.weight"].reshape(-1))
+    assert np.array_equal(take(4)[:2], sd["fc.bias"])
+    assert o == p.size
+
+
+def test_pack_rejects_bad_state_dicts():
+    sd = pkg.synth.make_state_dict("simple")
+    bad = dict(sd); del bad["fc.bias"]
+    with pytest.raises(KeyError):
+        ops.pack_state_dict(bad)
+    bad = dict(sd); bad["conv2.weight"] = np.zeros((64, 32, 5, 5), np.float32)
+    with pytest.raises(ValueError):
+        ops.pack_state_dict(bad)
+    s = nat.StateDict(); s.n_conv = 4; s.hidden = 256
+    out = np.zeros(16, np.float32)
+    assert nat.lib.ww_pack_weights_host(C.byref(s), out.ctypes.data) == nat.WW_EINVAL
+    assert b"n_conv" in nat.lib.ww_last_error()
+    assert nat.lib.ww_packed_weights_floats(5) == nat.WW_EINVAL
+
+
+def test_size_queries_do_not_need_a_gpu():
+    assert nat.lib.ww_workspace_bytes(4096, 2) >= 4096 * (2560 + 64) * 4
+    assert nat.lib.ww_cnn_scratch_bytes(16, 2) == 0 and nat.lib.ww_cnn_scratch_bytes(16, 3) == 16 * 80 * 64 * 32 * 4
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    # no CPU fallback anywhere: launches return WW_ENODEVICE, torch ops on CPU tensors raise
+    buf = np.zeros(16000, np.float32)
+    out = np.zeros(2560, np.float32)
+    rc = nat.lib.ww_logmel_f32(buf.ctypes.data, 1, 16000, 16000, 1, out.ctypes.data, None)
+    assert rc == nat.WW_ENODEVICE and b"no HIP device" in nat.lib.ww_last_error()
+    assert nat.lib.ww_init() == nat.WW_ENODEVICE
+    with pytest.raises(RuntimeError):
+        ops.logmel(torch.zeros(1, 16000), True)
+    with pytest.raises(RuntimeError):
+        torch.ops.wakeword_amd.forward_pcm(torch.zeros(1, 16000), torch.zeros(4), 2, True)
+    m = pkg.SimpleWakewordModel().eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 80, 32))
+    with pytest.raises(RuntimeError):
+        pkg.AudioProcessor().audio_to_mel(np.ones(16000, np.float32))
+
+
+def test_argument_checks_come_before_device_checks():
+    buf = np.zeros(16, np.float32)
+    assert nat.lib.ww_logmel_f32(buf.ctypes.data, 1, 16000, 20000, 1, buf.ctypes.data, None) == nat.WW_EINVAL
+    assert nat.lib.ww_logmel_f32(buf.ctypes.data + 4, 2, 16000, 16000, 1, buf.ctypes.data, None) == nat.WW_EINVAL
+    assert nat.lib.ww_cnn_pool_f32(buf.ctypes.data, 1, 40, buf.ctypes.data, 2, None, buf.ctypes.data, None) == nat.WW_EUNSUPPORTED
+    assert nat.lib.ww_lstm_fc_f32(buf.ctypes.data, 1, buf.ctypes.data, 7, buf.ctypes.data, None) == nat.WW_EINVAL
