@@ -43,6 +43,24 @@ MFMA_F32_PEAK = 157.3e12                               # flop/s, dense f32 MFMA 
 METRIC = "1s/16kHz clips/sec end-to-end (mel+CNN+LSTM)"
 
 
+def pmc_traffic(kernel, batch, arch):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json: FETCH_SIZE x2 +
+    WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process;
+    the newest committed pass for this batch/arch is quoted, else null."""
+    import glob
+    if batch != 4096 or arch != "simple":
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(path))["kernels"]
+            for name, d in k.items():
+                if kernel in name:
+                    return d["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(clips, sd, budget_s=20.0):
     """The reference path restated on the CPU (oracle/): per-clip numpy log-mel, then torch CPU layers."""
     from oracle import mel_oracle, model_oracle
@@ -59,13 +77,13 @@ def cpu_baseline(clips, sd, budget_s=20.0):
     with torch.no_grad():
         module(x[:2])
         t1 = time.perf_counter()
-        logits = module(x).numpy()
+        logits = np.concatenate([module(x[s:s + 64]).numpy() for s in range(0, n, 64)])   # config-1 sized batches
         t_model = time.perf_counter() - t1
     total = t_mel + t_model
     return {
         "value": n / total, "unit": "clips/s", "cores": int(torch.get_num_threads()), "kind": "port",
         "sample": f"{n} of the bench clips, one at a time: numpy/scipy float64-FFT log-mel (1 thread) then torch CPU "
-                  f"Conv2d/LSTM/Linear forward in one batch ({torch.get_num_threads()} threads)",
+                  f"Conv2d/LSTM/Linear forward in batches of 64 ({torch.get_num_threads()} threads)",
         "mel_clips_per_s": n / t_mel, "model_clips_per_s": n / t_model, "host_cpus": os.cpu_count(),
     }, np.stack(mels)[:, None].astype(np.float32), logits
 
@@ -172,13 +190,13 @@ def main():
                 "kernel": "cnn2_kernel<POOL> (conv1 + conv2 + ReLU + avg-pool, v_mfma_f32_32x32x2_f32)" if args.arch == "simple"
                           else "cnn2_kernel + cnn3_kernel (conv stack, v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma", "achieved": k2_ach / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": k2_ach / MFMA_F32_PEAK, "traffic": None,
+                "frac": k2_ach / MFMA_F32_PEAK, "traffic": pmc_traffic("cnn2_kernel", B, args.arch),
                 "flops_per_launch": k2_flops, "avg_launch_ms": k2_ms,
             },
             "stages": {
                 "K1_logmel": {"avg_ms": k1_ms, "bound": "hbm", "achieved_GBps": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / 1e9,
                               "peak_GBps": HBM_PEAK / 1e9, "frac": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / HBM_PEAK,
-                              "clips_per_s": B / (k1_ms * 1e-3),
+                              "clips_per_s": B / (k1_ms * 1e-3), "traffic": pmc_traffic("logmel_kernel", B, args.arch),
                               "f32_vector_frac": K1_FLOPS_PER_CLIP * B / (k1_ms * 1e-3) / MFMA_F32_PEAK},
                 "K2_cnn": {"avg_ms": k2_ms, "clips_per_s": B / (k2_ms * 1e-3)},
                 "K3_lstm_fc": {"avg_ms": k3_ms, "bound": "mfma", "achieved_TFLOPs": K3_FLOPS_PER_CLIP[args.arch] * B / (k3_ms * 1e-3) / 1e12,
@@ -188,8 +206,7 @@ def main():
             "device": nat.device_info(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_sample = 256
-            base, ref_mel, ref_logits = cpu_baseline(host[:n_sample], sd)
+            base, ref_mel, ref_logits = cpu_baseline(host, sd, budget_s=20.0)
             n = len(ref_mel)
             with torch.no_grad():
                 got_mel = ops.logmel(pcm[:n], True).cpu().numpy()

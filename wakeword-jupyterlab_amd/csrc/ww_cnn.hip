@@ -35,6 +35,9 @@ constexpr int kActFloats = 32 * kARows * kRS;          // 10,880
 constexpr int kMelFloats = (kH + 2) * kMelRS;          // 2,952
 constexpr int kC2LdsFloats = kActFloats + kMelFloats + 4 * 32;
 
+// ReLU that propagates NaN like torch's (F.relu(nan) = nan); fmaxf(nan, 0) would return 0
+__device__ __forceinline__ float relu(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads) {
     for (int i = tid; i < n; i += nthreads) p[i] = 0.f;
 }
@@ -63,7 +66,7 @@ __device__ __forceinline__ void conv1_band(const float* __restrict__ melt, float
             v = fmaf(w[0], m00, v); v = fmaf(w[1], m01, v); v = fmaf(w[2], m02, v);
             v = fmaf(w[3], m10, v); v = fmaf(w[4], m11, v); v = fmaf(w[5], m12, v);
             v = fmaf(w[6], m20, v); v = fmaf(w[7], m21, v); v = fmaf(w[8], m22, v);
-            v = inside ? fmaxf(v, 0.f) : 0.f;
+            v = inside ? relu(v) : 0.f;
             act[(ci * kARows + q) * kRS + x + 1] = v;
         }
     }
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void cnn2_kernel(const float* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
-                        const float v = fmaxf(acc[r][j] + bias, 0.f);
+                        const float v = relu(acc[r][j] + bias);
                         pool += (col < width) ? v : 0.f;
                     }
             } else {
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(256, 2) void cnn2_kernel(const float* __restrict__ 
                     for (int g = 0; g < 4; ++g) {
                         const int col0 = 8 * g + 4 * h;
                         float4 v;
-                        v.x = (col0 + 0 < width) ? fmaxf(acc[r][4 * g + 0] + bias, 0.f) : 0.f;
-                        v.y = (col0 + 1 < width) ? fmaxf(acc[r][4 * g + 1] + bias, 0.f) : 0.f;
-                        v.z = (col0 + 2 < width) ? fmaxf(acc[r][4 * g + 2] + bias, 0.f) : 0.f;
-                        v.w = (col0 + 3 < width) ? fmaxf(acc[r][4 * g + 3] + bias, 0.f) : 0.f;
+                        v.x = (col0 + 0 < width) ? relu(acc[r][4 * g + 0] + bias) : 0.f;
+                        v.y = (col0 + 1 < width) ? relu(acc[r][4 * g + 1] + bias) : 0.f;
+                        v.z = (col0 + 2 < width) ? relu(acc[r][4 * g + 2] + bias) : 0.f;
+                        v.w = (col0 + 3 < width) ? relu(acc[r][4 * g + 3] + bias) : 0.f;
                         *reinterpret_cast<float4*>(dst + col0) = v;
                     }
                 }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
-                        const float v = fmaxf(acc[r][j] + xch[((nt * 4 + r) * 16 + j) * 64 + lane] + bias, 0.f);
+                        const float v = relu(acc[r][j] + xch[((nt * 4 + r) * 16 + j) * 64 + lane] + bias);
                         pool += (col < width) ? v : 0.f;
                     }
             }

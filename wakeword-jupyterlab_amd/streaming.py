@@ -45,6 +45,10 @@ class StreamingDetector:
         """Push one hop [n_mics, hop_samples] (or reuse whatever is in `hop_buf`) and enqueue the graph.
         Returns `self.prob` (softmax p(wakeword) per mic), valid once `self.stream` has caught up."""
         if hop is not None:
+            if hop.device.type == "cuda":
+                # `hop` was produced on the caller's stream: order our stream behind it before reading it
+                self._stream.wait_stream(torch.cuda.current_stream(self.device))
+                hop.record_stream(self._stream)
             with torch.cuda.stream(self._stream):
                 self.hop_buf.copy_(hop, non_blocking=True)
         with torch.cuda.device(self.device):
