@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU per step")
     ap.add_argument("--arch", default="simple", choices=["simple", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-math", default=None, choices=["f32", "f16x3"], help="conv2 arithmetic (default: library default)")
     args = ap.parse_args()
 
     import wakeword_jupyterlab_amd as pkg
@@ -112,6 +113,9 @@ def main():
     from wakeword_jupyterlab_amd import ops
 
     ops.init()
+    if args.conv_math:
+        ops.set_conv_math(args.conv_math)
+    conv_math = ops.get_conv_math()
     B = args.batch
     n_conv = 2 if args.arch == "simple" else 3
     sd = pkg.synth.make_state_dict(args.arch, seed=1234)

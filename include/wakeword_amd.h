@@ -67,6 +67,17 @@ WW_API int ww_init(void);
 /* Device facts used by bench.py for the roofline denominator: number of CUs, max clock (kHz). */
 WW_API int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len);
 
+/* Arithmetic of the conv2 implicit GEMM (94 of the model's 96.5 MFLOP per clip); process-wide, default F32.
+ *   WW_CONV_MATH_F32    v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (an fmaf chain)
+ *   WW_CONV_MATH_F16X3  each fp32 operand carried as two f16 halves (22 significant bits), every product block as
+ *                       three v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative error per product
+ *                       (PyTorch's own default for convolutions on the reference's GPU is TF32, 2^-11), 3/16 of
+ *                       the matrix-core cycles.  Requires conv1 activations < 65504. */
+#define WW_CONV_MATH_F32 0
+#define WW_CONV_MATH_F16X3 1
+WW_API int ww_set_conv_math(int mode);
+WW_API int ww_get_conv_math(void);
+
 /* ---- front-end tables, host side (no GPU needed; lets CPU tests check them) ------------------ */
 /* librosa.filters.mel(sr=16000, n_fft=2048, n_mels=80, fmin=0, fmax=8000, htk=False,
  * norm='slaney') as used by wakeword_training_script.py:89-98 -> [80][1025] float32. */

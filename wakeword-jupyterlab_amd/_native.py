@@ -16,7 +16,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwakeword_amd.so")
+LIB_PATH = os.environ.get("WW_LIB_OVERRIDE") or os.path.join(_HERE, "libwakeword_amd.so")   # override: ablation builds only
 
 WW_OK, WW_EINVAL, WW_ENODEVICE, WW_EHIP, WW_EUNSUPPORTED = 0, -1, -2, -3, -4
 ABI_VERSION = 1
@@ -43,6 +43,8 @@ PROTOTYPES = {
     "ww_abi_version": (C.c_int, []),
     "ww_last_error": (C.c_char_p, []),
     "ww_init": (C.c_int, []),
+    "ww_set_conv_math": (C.c_int, [C.c_int]),
+    "ww_get_conv_math": (C.c_int, []),
     "ww_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "ww_mel_filterbank_host": (C.c_int, [C.c_void_p]),
     "ww_hann_window_host": (C.c_int, [C.c_void_p]),

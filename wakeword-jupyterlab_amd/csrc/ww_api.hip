@@ -68,6 +68,10 @@ const LogmelTables* device_tables() {
     return devp;
 }
 
+static int g_conv_math = 0;
+int conv_math_mode() { return g_conv_math; }
+void set_conv_math_mode(int mode) { g_conv_math = mode; }
+
 static int64_t align256(int64_t b) { return (b + 255) & ~int64_t(255); }
 int64_t cnn_scratch_bytes(int64_t n, int n_conv);
 
@@ -170,6 +174,13 @@ static int streamer_enqueue(ww_streamer* s, const float* hop_dev, float* prob_de
 }
 
 extern "C" {
+
+int ww_set_conv_math(int mode) {
+    if (mode != WW_CONV_MATH_F32 && mode != WW_CONV_MATH_F16X3) return fail(WW_EINVAL, "unknown conv math mode %d", mode);
+    set_conv_math_mode(mode);
+    return WW_OK;
+}
+int ww_get_conv_math(void) { return conv_math_mode(); }
 
 int ww_init(void) {
     if (int rc = require_gfx950()) return rc;

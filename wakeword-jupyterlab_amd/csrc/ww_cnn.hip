@@ -183,6 +183,225 @@ __global__ __launch_bounds__(256, 2) void cnn2_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv1 + conv2 + pool with SPLIT-PRECISION conv2: every fp32 operand is carried as two f16 halves
+// (x ~= hi + lo, 22 significant bits) and each product block runs as three f16 MFMAs accumulating in fp32:
+//     a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi          (the dropped a_lo*w_lo is < 2^-22 relative)
+// v_mfma_f32_32x32x16_f16 does 16x the flops per cycle of v_mfma_f32_32x32x2_f32, so the matrix pipe needs
+// 3/16 of the cycles of the exact-f32 kernel.  f16 products (11 x 11 bits) are exact in the fp32 accumulator.
+// Weights are pre-scaled by 2^S on the host (both halves normal f16); the accumulator is descaled by 2^-S.
+//
+// LDS tile: channels-last, one 144-byte record per image position:  [32 ci hi f16][32 ci lo f16][16 B pad]
+// (the pad makes consecutive positions 36 dwords apart: ds_read_b128 / ds_write_b128 conflict-free).
+// k-step = (channel block cb of 16, dx, dy): lane (x, h) reads the 8 channels 16cb+8h.. of position (q, x+dx)
+// with ONE ds_read_b128 per half; an input row's fragments serve every (output row, dy) pair that touches it.
+// ------------------------------------------------------------------------------------------------
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+constexpr int kPosBytes = 144;                               // one position record
+constexpr int kHRowBytes = kRS * kPosBytes;                  // 34 positions per tile row
+constexpr int kHActBytes = kARows * kHRowBytes;              // 48,960
+
+__device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b) {
+    return uint32_t(__builtin_bit_cast(uint16_t, a)) | (uint32_t(__builtin_bit_cast(uint16_t, b)) << 16);
+}
+
+// conv1 for one band straight into the split f16 tile.  wave w computes channels 8w..8w+7 of (row q, column x)
+// and stores them as one 16-byte hi block and one 16-byte lo block.
+__device__ __forceinline__ void conv1_band_split(const float* __restrict__ melt, char* __restrict__ act,
+                                                 const float* __restrict__ w1, const float* __restrict__ b1, int y0,
+                                                 int width, int wave, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int i = 0; i < kARows / 2; ++i) {
+        const int q = 2 * i + h;
+        const int y = y0 - 1 + q;
+        const bool inside = (y >= 0) && (y < kH) && (x < width);
+        const float* m = melt + (inside ? y : 0) * kMelRS + x;
+        const float m00 = m[0], m01 = m[1], m02 = m[2];
+        const float m10 = m[kMelRS], m11 = m[kMelRS + 1], m12 = m[kMelRS + 2];
+        const float m20 = m[2 * kMelRS], m21 = m[2 * kMelRS + 1], m22 = m[2 * kMelRS + 2];
+        _Float16 hi[8], lo[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ci = 8 * wave + u;
+            const float* w = w1 + ci * 9;
+            float v = b1[ci];
+            v = fmaf(w[0], m00, v); v = fmaf(w[1], m01, v); v = fmaf(w[2], m02, v);
+            v = fmaf(w[3], m10, v); v = fmaf(w[4], m11, v); v = fmaf(w[5], m12, v);
+            v = fmaf(w[6], m20, v); v = fmaf(w[7], m21, v); v = fmaf(w[8], m22, v);
+            v = inside ? relu(v) : 0.f;
+            hi[u] = static_cast<_Float16>(v);
+            lo[u] = static_cast<_Float16>(v - static_cast<float>(hi[u]));
+        }
+        char* rec = act + (q * kRS + x + 1) * kPosBytes + wave * 16;
+        u32x4 vh, vl;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { vh[d] = pack_h2(hi[2 * d], hi[2 * d + 1]); vl[d] = pack_h2(lo[2 * d], lo[2 * d + 1]); }
+        *reinterpret_cast<u32x4*>(rec) = vh;
+        *reinterpret_cast<u32x4*>(rec + 64) = vl;
+    }
+}
+
+// Workgroup = 8 waves with fixed roles, one workgroup per CU (persistent over clips):
+//   waves 0-3  CONSUMERS: (row group, N-tile) MFMA tiles of the current band + bias/ReLU/pool epilogue
+//   waves 4-7  PRODUCERS: conv1 of the NEXT band on the VALU into the other half of a double-buffered LDS tile,
+//              and the next clip's log-mel image into a double-buffered mel tile
+// so each SIMD hosts one matrix-pipe wave and one VALU wave that overlap in hardware; one barrier per band.
+constexpr int kC2hLdsBytes2 = 2 * kHActBytes + 2 * kMelFloats * 4 + 4 * 32 * 4;
+
+template <bool POOL>
+__global__ __launch_bounds__(512, 2) void cnn2h_kernel(const float* __restrict__ mel, int n, int width,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const u32x4* __restrict__ wH, const float* __restrict__ hs,
+                                                       const float* __restrict__ b2, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* act0 = ldsb;                                                       // 2 x [10][34] records of 144 B
+    float* melt0 = reinterpret_cast<float*>(ldsb + 2 * kHActBytes);          // 2 x [82][36]
+    float* red = melt0 + 2 * kMelFloats;                                     // [4][32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int nt = wave & 1, rg = (wave >> 1) & 1;
+    const int x = lane & 31, h = lane >> 5;
+    const int ptid = tid - 256;                                              // producer thread index 0..255
+
+    half8 bh[18], bl[18];
+    float bias = 0.f, descale = 0.f;
+    if (consumer) {
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            bh[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 0) * 64 + lane]);
+            bl[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 1) * 64 + lane]);
+        }
+        bias = b2[32 * nt + x];
+        descale = hs[0];
+    }
+    for (int i = tid; i < kC2hLdsBytes2 / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
+    __syncthreads();
+
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);   // clips blockIdx.x + i*gridDim.x
+    const int steps = my_clips * (kH / kBand);
+    const float inv_area = 1.0f / float(kH * width);
+
+    auto load_mel = [&](int k) {     // producers: log-mel image of this workgroup's k-th clip -> melt[k & 1]
+        const float* __restrict__ src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kH * width;
+        float* mt = melt0 + (k & 1) * kMelFloats;
+        for (int i = ptid; i < kH * width; i += 256) {
+            const int y = i / width, xx = i - y * width;
+            mt[(y + 1) * kMelRS + xx + 1] = src[i];
+        }
+    };
+    auto produce = [&](int g) {      // producers: conv1 of step g (clip g/10, band g%10) -> act[g & 1]
+        const int k = g / (kH / kBand), band = g - k * (kH / kBand);
+        conv1_band_split(melt0 + (k & 1) * kMelFloats, act0 + (g & 1) * kHActBytes, w1, b1, band * kBand, width,
+                         wave - 4, lane);
+    };
+
+    if (!consumer && steps > 0) load_mel(0);
+    __syncthreads();
+    if (!consumer && steps > 0) {
+        produce(0);
+        if (my_clips > 1) load_mel(1);
+    }
+    __syncthreads();
+
+    float pool = 0.f;
+    for (int g = 0; g < steps; ++g) {
+        const int k = g / (kH / kBand), band = g - k * (kH / kBand);
+        if (consumer) {
+            if constexpr (POOL) {
+                if (band == 0 && g > 0 && wave == 0) {      // previous clip's pooled sums are complete in `red`
+                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k - 1) * gridDim.x;
+                    out[clip * 64 + lane] = (red[(lane >> 5) * 32 + (lane & 31)] + red[(2 + (lane >> 5)) * 32 + (lane & 31)]) * inv_area;
+                }
+            }
+            const char* ap = act0 + (g & 1) * kHActBytes + ((rg * 4) * kRS + x) * kPosBytes + h * 16;
+            f32x16 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+            // 36 fragment steps it = (cb*3 + dx)*6 + q, software-pipelined one step ahead: with a single matrix-pipe
+            // wave per SIMD nothing else hides the ds_read_b128 latency.
+            auto frag = [&](int it, int half) -> half8 {
+                const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
+                return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + dx) * kPosBytes + cb * 32 + half * 64));
+            };
+            half8 ah = frag(0, 0), al = frag(0, 1);
+#ifdef WW_ABL_NO_MFMA
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) { asm volatile("" :: "v"(bh[ks]), "v"(bl[ks])); }
+            acc[0][0] = float(ah[0]) + float(al[0]);
+#else
+#pragma unroll
+            for (int it = 0; it < 36; ++it) {
+                half8 ahn = ah, aln = al;
+                if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
+                const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = q - dy;
+                    if (r < 0 || r > 3) continue;
+                    const int ks = (cb * 3 + dx) * 3 + dy;
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[r], 0, 0, 0);
+                }
+                ah = ahn; al = aln;
+            }
+#endif
+            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+            if constexpr (POOL) {
+                if (band == 0) pool = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
+                        const float v = relu(fmaf(acc[r][j], descale, bias));
+                        pool += (col < width) ? v : 0.f;
+                    }
+                if (band == kH / kBand - 1) {
+                    const float p2 = pool + __shfl_xor(pool, 32);
+                    if (lane < 32) red[wave * 32 + lane] = p2;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = band * kBand + rg * 4 + r;
+                    float* dst = out + ((clip * kH + y) * 64 + 32 * nt + x) * kW;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int col0 = 8 * gq + 4 * h;
+                        float4 v;
+                        v.x = (col0 + 0 < width) ? relu(fmaf(acc[r][4 * gq + 0], descale, bias)) : 0.f;
+                        v.y = (col0 + 1 < width) ? relu(fmaf(acc[r][4 * gq + 1], descale, bias)) : 0.f;
+                        v.z = (col0 + 2 < width) ? relu(fmaf(acc[r][4 * gq + 2], descale, bias)) : 0.f;
+                        v.w = (col0 + 3 < width) ? relu(fmaf(acc[r][4 * gq + 3], descale, bias)) : 0.f;
+                        *reinterpret_cast<float4*>(dst + col0) = v;
+                    }
+                }
+            }
+        } else if (g + 1 < steps) {
+#ifndef WW_ABL_NO_CONV1
+            produce(g + 1);
+#endif
+            const int k1 = (g + 1) / (kH / kBand);
+            if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);   // two clips ahead of the MFMAs
+        }
+        __syncthreads();
+    }
+    if constexpr (POOL) {
+        if (consumer && wave == 0 && steps > 0) {
+            const int64_t clip = int64_t(blockIdx.x) + int64_t(my_clips - 1) * gridDim.x;
+            out[clip * 64 + lane] = (red[(lane >> 5) * 32 + (lane & 31)] + red[(2 + (lane >> 5)) * 32 + (lane & 31)]) * inv_area;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv3 (64->128) + ReLU + pool for the 3-conv WakewordModel.  512 threads: wave = (K-half kh, N-tile nt);
 // the two K-halves of an N-tile are summed through LDS before bias/ReLU.  Band = 4 output rows.
 // in = relu(conv2) as [n][80][64][32]; out = pooled [n][128].
@@ -272,6 +491,21 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
     const int64_t resident = int64_t(device_cu_count()) * 2;
     const int grid = int(n < resident ? n : resident);
     const size_t lds2 = sizeof(float) * kC2LdsFloats;
+    const bool split = conv_math_mode() == 1;
+    const int grid_h = int(n < device_cu_count() ? n : device_cu_count());     // one 8-wave workgroup per CU
+    static bool h_attr_set = false;     // > 64 KiB of dynamic LDS needs the opt-in once per process
+    if (split && !h_attr_set) {
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2hLdsBytes2));
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2hLdsBytes2));
+        h_attr_set = true;
+    }
+    const u32x4* wH = reinterpret_cast<const u32x4*>(packed + L.conv2_h);
+    if (n_conv == 2 && split) {
+        hipLaunchKernelGGL(cnn2h_kernel<true>, dim3(grid_h), dim3(512), kC2hLdsBytes2, stream, mel, int(n), width,
+                           packed + L.conv1_w, packed + L.conv1_b, wH, packed + L.conv2_hs, packed + L.conv2_b, pooled);
+        WW_HIP(hipGetLastError());
+        return WW_OK;
+    }
     if (n_conv == 2) {
         hipLaunchKernelGGL(cnn2_kernel<true>, dim3(grid), dim3(256), lds2, stream, mel, int(n), width,
                            packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, pooled);
@@ -280,8 +514,12 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
     }
     if (!scratch) return fail(WW_EINVAL, "n_conv == 3 needs ww_cnn_scratch_bytes() of scratch");
     float* mid = static_cast<float*>(scratch);
-    hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid), dim3(256), lds2, stream, mel, int(n), width,
-                       packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, mid);
+    if (split)
+        hipLaunchKernelGGL(cnn2h_kernel<false>, dim3(grid_h), dim3(512), kC2hLdsBytes2, stream, mel, int(n), width,
+                           packed + L.conv1_w, packed + L.conv1_b, wH, packed + L.conv2_hs, packed + L.conv2_b, mid);
+    else
+        hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid), dim3(256), lds2, stream, mel, int(n), width,
+                           packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, mid);
     WW_HIP(hipGetLastError());
     const int grid3 = int(n < device_cu_count() ? n : device_cu_count());
     static bool lds_attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process

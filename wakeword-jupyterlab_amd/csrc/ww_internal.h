@@ -29,9 +29,11 @@ constexpr int kMels = WW_N_MELS;
 constexpr int kFrames = WW_N_FRAMES;
 constexpr int kBins = WW_N_BINS;
 
-// The mel matrix (2004 non-zeros, <=2 filters per bin, every filter one contiguous run of 9..75 bins)
-// is cut into fixed-size pieces of kPieceLen consecutive bins of ONE filter (zero-weight padded), so
-// that every lane of the mel stage runs the same trip count.
+// The mel matrix (2004 non-zeros, <=2 filters per bin, every filter one contiguous run of 9..75 bins) is cut
+// into PIECES: (filter f, aligned window of 8 bins [8m, 8m+8)) with 8 weights (zero outside the filter).
+// 317 real pieces -> 5 rounds of 64 lane-slots; every lane of the mel stage runs the same trip count and reads
+// its 8 power bins with two aligned ds_read_b128.  Slot order = sorted by window, dealt out so that the 16 lanes
+// of one ds_read_b128 hardware group read neighbouring windows (conflict-free, mostly broadcast).
 constexpr int kPieceLen = 8;
 constexpr int kPieceRounds = 5;             // pieces per lane-slot
 constexpr int kPieceSlots = 64;             // lane-slots
@@ -42,9 +44,9 @@ struct LogmelTables {
     float2 tw1[7][128];           // W_1024^(n' * k1),  k1 = 1..7, n' = 0..127
     float2 tw2[7][16];            // W_128^(n'' * k2),  k2 = 1..7, n'' = 0..15
     float2 twp[512];              // W_2048^k, k = 0..511, except twp[0] = W_2048^512 (lane 0 takes bin 512)
-    int32_t piece_k0[kPieces];    // first bin of the piece
-    float piece_w[kPieces][kPieceLen];
-    int32_t filt_p0[kMels];       // first piece of filter f
+    float piece_w[2][kPieces][4]; // [half][slot index c*64+lane][4]: weights of bins 8m+4*half .. +3
+    int32_t piece_info[kPieces];  // (8m) | (output position << 16); output positions are filter-major
+    int32_t filt_p0[kMels];       // first output position of filter f
     int32_t filt_cnt[kMels];      // number of pieces of filter f
 };
 
@@ -74,6 +76,9 @@ struct PackedLayout {
     int64_t l1_b;      // [768]
     int64_t fc_w;      // [2][256]
     int64_t fc_b;      // [2] (+2 pad)
+    // split-precision image of conv2 for the f16x3 kernel: W * 2^S = hi + lo (two f16), MFMA 32x32x16 B-operand order
+    int64_t conv2_h;   // [2 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64 lanes][4 dwords = 8 f16]
+    int64_t conv2_hs;  // [4]: 2^-S (descale applied to the f32 accumulator), S, 0, 0
     int64_t total;
 };
 PackedLayout packed_layout(int n_conv);
@@ -86,6 +91,9 @@ int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_
                   float* logmel, hipStream_t stream);
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
                     float* pooled, hipStream_t stream);
+// conv math: 0 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split (3 x v_mfma_f32_32x32x16_f16 per product block)
+int conv_math_mode();
+void set_conv_math_mode(int mode);
 int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_conv, float* logits,
                    float* prob /*nullable*/, hipStream_t stream);
 

@@ -21,13 +21,25 @@ namespace ww {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
-// wave slab: 1024 complex = 2048 floats, +4 floats (keeps 16-byte alignment) so the 4 power rows of a
-// mel round start on different banks
+// wave slab: 1024 complex = 2048 floats (+4 keeps 16-byte alignment and staggers the slabs over the banks)
 constexpr int kSlab = 2048 + 4;
 constexpr int kMelStride = kFrames + 1;
-// piece table copy in LDS: [kPieces][8] weights + [kPieces] first bins (ints), then filter -> piece ranges
-constexpr int kLdsFloats = kWavesPerBlock * kSlab + kPieces * kWavesPerBlock + kMels * kMelStride + 16 +
-                           kPieces * kPieceLen + kPieces + 2 * kMels;
+// LDS map (floats): slabs | mel | reduce scratch | sparse-mel tables | twiddle tables | window.
+// The per-wave piece sums live in the upper half of the wave's slab (the power spectrum only needs floats 0..1024).
+constexpr int kPartialInSlab = 1032;
+static_assert(kPartialInSlab + kPieces <= kSlab, "piece sums must fit behind the power spectrum");
+constexpr int kOffMel = kWavesPerBlock * kSlab;
+constexpr int kOffRed = kOffMel + kMels * kMelStride;
+constexpr int kOffPw = kOffRed + 16;                    // [2][kPieces][4]
+constexpr int kOffPinfo = kOffPw + 2 * kPieces * 4;     // [kPieces] ints
+constexpr int kOffFp0 = kOffPinfo + kPieces;            // [80] ints
+constexpr int kOffFcnt = kOffFp0 + kMels;               // [80] ints
+constexpr int kOffTw2 = kOffFcnt + kMels;               // [7][16] float2
+constexpr int kOffTwp = kOffTw2 + 7 * 16 * 2;           // [512] float2
+constexpr int kOffTw1 = kOffTwp + 512 * 2;              // [7][128] float2
+constexpr int kOffWin = kOffTw1 + 7 * 128 * 2;          // [2048]
+constexpr int kLdsFloats = kOffWin + kNfft;
+static_assert(kOffPw % 4 == 0 && kOffTw2 % 4 == 0 && kOffTwp % 2 == 0 && kOffTw1 % 4 == 0 && kOffWin % 4 == 0, "LDS table alignment");
 
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -112,103 +124,123 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                                                              const LogmelTables* __restrict__ tb,
                                                              float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* slabs = lds;                                         // [4][kSlab]
-    float* partial = slabs + kWavesPerBlock * kSlab;            // [kPieces][4]
-    float* mel = partial + kPieces * kWavesPerBlock;            // [80][33]
-    float* red = mel + kMels * kMelStride;                      // [16]
-    float* pw = red + 16;                                       // [kPieces][8]   (16-byte aligned)
-    int* pk0 = reinterpret_cast<int*>(pw + kPieces * kPieceLen);   // [kPieces]
-    int* fp0 = pk0 + kPieces;                                   // [80]
-    int* fcnt = fp0 + kMels;                                    // [80]
+    float* mel = lds + kOffMel;                                 // [80][33]
+    float* red = lds + kOffRed;                                 // [16]
+    const float4* pw4 = reinterpret_cast<const float4*>(lds + kOffPw);   // [2][kPieces]
+    const int* pinfo = reinterpret_cast<const int*>(lds + kOffPinfo);
+    const int* fp0 = reinterpret_cast<const int*>(lds + kOffFp0);
+    const int* fcnt = reinterpret_cast<const int*>(lds + kOffFcnt);
+    const float4* tw2_4 = reinterpret_cast<const float4*>(lds + kOffTw2);   // [7][8] float4 = two twiddles each
+    const float2* twp_2 = reinterpret_cast<const float2*>(lds + kOffTwp);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* slab = slabs + wave * kSlab;
+    float* slab = lds + wave * kSlab;
     float2* slab2 = reinterpret_cast<float2*>(slab);
     float4* slab4 = reinterpret_cast<float4*>(slab);
+    float* partial = slab + kPartialInSlab;                     // this wave's piece sums, filter-major
+    const float4* tw1_4 = reinterpret_cast<const float4*>(lds + kOffTw1);   // [7][64] float4 = twiddles of n' = 2l, 2l+1
+    const float4* win4 = reinterpret_cast<const float4*>(lds + kOffWin);
 
-    // ---- lane constants, kept in registers across all frames of all clips ----
-    float4 t1[7];     // W_1024^{n' k1} for n' = 2*lane, 2*lane+1
-    float4 t2[7];     // W_128^{n'' k2} for n'' = 2*(lane&7), +1
-    float2 tp[8];     // W_2048^k for k = lane + 64 j (lane 0, j 0: k = 512)
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        t1[k] = *reinterpret_cast<const float4*>(&tb->tw1[k][2 * lane]);
-        t2[k] = *reinterpret_cast<const float4*>(&tb->tw2[k][2 * (lane & 7)]);
+    // ---- all tables into LDS once per workgroup (conflict-free, lane-contiguous reads) ----
+    for (int i = tid; i < 2 * kPieces * 4; i += kThreads) lds[kOffPw + i] = (&tb->piece_w[0][0][0])[i];
+    for (int i = tid; i < kPieces; i += kThreads) reinterpret_cast<int*>(lds)[kOffPinfo + i] = tb->piece_info[i];
+    if (tid < kMels) {
+        reinterpret_cast<int*>(lds)[kOffFp0 + tid] = tb->filt_p0[tid];
+        reinterpret_cast<int*>(lds)[kOffFcnt + tid] = tb->filt_cnt[tid];
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) tp[j] = tb->twp[lane + 64 * j];
-
+    for (int i = tid; i < 7 * 16 * 2; i += kThreads) lds[kOffTw2 + i] = (&tb->tw2[0][0].x)[i];
+    for (int i = tid; i < 512 * 2; i += kThreads) lds[kOffTwp + i] = (&tb->twp[0].x)[i];
+    for (int i = tid; i < 7 * 128 * 2; i += kThreads) lds[kOffTw1 + i] = (&tb->tw1[0][0].x)[i];
+    for (int i = tid; i < kNfft; i += kThreads) lds[kOffWin + i] = tb->window[i];
     const int ring_pos = ring_pos_p ? *ring_pos_p : 0;
-
-    // sparse-mel tables live in LDS for the life of the workgroup (read every round by every thread)
-    for (int i = tid; i < kPieces * kPieceLen; i += kThreads) pw[i] = (&tb->piece_w[0][0])[i];
-    for (int i = tid; i < kPieces; i += kThreads) pk0[i] = tb->piece_k0[i];
-    if (tid < kMels) { fp0[tid] = tb->filt_p0[tid]; fcnt[tid] = tb->filt_cnt[tid]; }
     __syncthreads();
+    // this lane's filters in the per-frame combine: f = lane and f = lane + 64 (< 80)
+    const int my_p0a = fp0[lane], my_cnta = fcnt[lane];
+    const int my_p0b = lane + 64 < kMels ? fp0[lane + 64] : 0, my_cntb = lane + 64 < kMels ? fcnt[lane + 64] : 0;
+
+    // exchange layouts (float4 units inside the wave slab), chosen so that every ds_read/write_b128 below is
+    // bank-conflict free for the hardware's 16-lane groups:
+    //   X1: y[k1][n'/2]       at k1*64 + ((n'/2) ^ (8 * ((k1>>1)&1)))
+    //   X2: u[reader lane][m] at reader*8 + (m ^ ((reader>>1)&7)),  reader = 8*k1 + k2, m = n''/2
+    //   Z : Z[k]              at float2 index k ^ (((k>>4)&3) << 1)
+    const int k1r = lane >> 3, jr = lane & 7;                   // pass-2 role: (k1, j)
 
 #pragma unroll 1
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
         const float* __restrict__ x = pcm + int64_t(clip) * clip_stride;
         float peak = 0.f;
+        // the samples of a frame are fetched one frame ahead (8 x dwordx4 per lane in flight under the FFT)
+        float4 sn[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1)
+            sn[n1] = load_samples(x, wave * kHop - kNfft / 2 + 4 * lane + 256 * n1, clip_len, ring_pos_p, ring_pos, ring_len);
 
 #pragma unroll 1
         for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
             const int frame = round * kWavesPerBlock + wave;
-            const int base = frame * kHop - kNfft / 2 + 4 * lane;
+            const int base_next = (frame + kWavesPerBlock) * kHop - kNfft / 2 + 4 * lane;
 
             // ---- load + window: lane holds z[128 n1 + 2 lane + q], q = 0,1, n1 = 0..7 ----
             float2 za[8], zb[8];
-            int woff = 4 * lane;
-            asm volatile("" : "+v"(woff));   // keep the (L1-resident) window loads inside the loop: 32 fewer live VGPRs
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
-                const float4 s = load_samples(x, base + 256 * n1, clip_len, ring_pos_p, ring_pos, ring_len);
-                const float4 w = *reinterpret_cast<const float4*>(&tb->window[256 * n1 + woff]);
+                const float4 s = sn[n1];
+                const float4 w = win4[64 * n1 + lane];
                 peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
                 za[n1] = make_float2(s.x * w.x, s.y * w.y);
                 zb[n1] = make_float2(s.z * w.z, s.w * w.w);
             }
-            // ---- pass 1: radix 8 over n1 (stride 128), twiddle W_1024^{n' k1}, store y[k1][n'] ----
+            if (round + 1 < kFrames / kWavesPerBlock) {
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1)
+                    sn[n1] = load_samples(x, base_next + 256 * n1, clip_len, ring_pos_p, ring_pos, ring_len);
+            }
+            // ---- pass 1: radix 8 over n1 (stride 128), twiddle W_1024^{n' k1}, store X1 ----
             dft8(za);
             dft8(zb);
             slab4[lane] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) {
-                const float2 a = cmul(za[k1], make_float2(t1[k1 - 1].x, t1[k1 - 1].y));
-                const float2 b = cmul(zb[k1], make_float2(t1[k1 - 1].z, t1[k1 - 1].w));
-                slab4[k1 * 64 + lane] = make_float4(a.x, a.y, b.x, b.y);     // float2 index k1*128 + 2*lane
+                const float4 t = tw1_4[(k1 - 1) * 64 + lane];
+                const float2 a = cmul(za[k1], make_float2(t.x, t.y));
+                const float2 b = cmul(zb[k1], make_float2(t.z, t.w));
+                slab4[k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)))] = make_float4(a.x, a.y, b.x, b.y);
             }
             lds_order();
-            // ---- pass 2: lane = (k1 = lane>>3, j = lane&7): radix 8 over n2 of y[k1][16 n2 + 2j + q] ----
+            // ---- pass 2: lane = (k1, j): radix 8 over n2 of y[k1][16 n2 + 2j + q]; twiddle W_128; store X2 ----
             {
-                const int k1 = lane >> 3, j = lane & 7;
+                const int sw1 = 8 * ((k1r >> 1) & 1);
 #pragma unroll
                 for (int n2 = 0; n2 < 8; ++n2) {
-                    const float4 v = slab4[k1 * 64 + n2 * 8 + j];
+                    const float4 v = slab4[k1r * 64 + ((n2 * 8 + jr) ^ sw1)];
                     za[n2] = make_float2(v.x, v.y);
                     zb[n2] = make_float2(v.z, v.w);
                 }
                 lds_order();
                 dft8(za);
                 dft8(zb);
-                // u[k1][k2][n''] at float2 index k1*128 + k2*16 + n''
-                slab4[k1 * 64 + j] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
 #pragma unroll
-                for (int k2 = 1; k2 < 8; ++k2) {
-                    const float2 a = cmul(za[k2], make_float2(t2[k2 - 1].x, t2[k2 - 1].y));
-                    const float2 b = cmul(zb[k2], make_float2(t2[k2 - 1].z, t2[k2 - 1].w));
-                    slab4[k1 * 64 + k2 * 8 + j] = make_float4(a.x, a.y, b.x, b.y);
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    float2 a = za[k2], b = zb[k2];
+                    if (k2 > 0) {
+                        const float4 t = tw2_4[(k2 - 1) * 8 + jr];
+                        a = cmul(a, make_float2(t.x, t.y));
+                        b = cmul(b, make_float2(t.z, t.w));
+                    }
+                    const int reader = 8 * k1r + k2;
+                    slab4[reader * 8 + (jr ^ ((reader >> 1) & 7))] = make_float4(a.x, a.y, b.x, b.y);
                 }
             }
             lds_order();
             // ---- pass 3: lane = (k1, k2): radix 16 over n'' -> Z[k1 + 8 k2 + 64 k''] ----
             {
                 float2 u[16];
+                const int sw2 = (lane >> 1) & 7;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
-                    const float4 v = slab4[lane * 8 + m];                    // float2 index lane*16 + 2m
+                    const float4 v = slab4[lane * 8 + (m ^ sw2)];
                     u[2 * m] = make_float2(v.x, v.y);
                     u[2 * m + 1] = make_float2(v.z, v.w);
                 }
@@ -216,7 +248,10 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 dft16(u);
                 const int lp = (lane >> 3) + 8 * (lane & 7);
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) slab2[lp + 64 * kk] = u[kk];
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int k = lp + 64 * kk;
+                    slab2[k ^ (((k >> 4) & 3) << 1)] = u[kk];
+                }
             }
             lds_order();
             // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
@@ -225,55 +260,65 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = (j == 0 && lane == 0) ? 512 : lane + 64 * j;
-                    a[j] = slab2[k];
-                    b[j] = slab2[1024 - k];
+                    const int kb = 1024 - k;
+                    a[j] = slab2[k ^ (((k >> 4) & 3) << 1)];
+                    b[j] = slab2[kb ^ (((kb >> 4) & 3) << 1)];
                 }
                 lds_order();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = (j == 0 && lane == 0) ? 512 : lane + 64 * j;
+                    const float2 tw = twp_2[lane + 64 * j];
                     const float2 e = make_float2(0.5f * (a[j].x + b[j].x), 0.5f * (a[j].y - b[j].y));
                     const float2 o = make_float2(0.5f * (a[j].y + b[j].y), 0.5f * (b[j].x - a[j].x));   // (a - conj b)/(2i)
-                    const float2 t = cmul(o, tp[j]);
+                    const float2 t = cmul(o, tw);
                     const float2 p = e + t, m = e - t;
                     slab[k] = fmaf(p.x, p.x, p.y * p.y);
                     slab[1024 - k] = fmaf(m.x, m.x, m.y * m.y);
                 }
+                if (lane == 0) slab[0] = 0.f;     // bin 0 carries zero mel weight but is read by window 0
             }
-            __syncthreads();   // (A) the 4 power spectra of this round are complete
-
-            // ---- sparse mel over the round's 4 frames: thread = (frame-in-round, slot) ----
+            lds_order();
+            // ---- sparse mel of THIS wave's frame: lane = slot, 5 pieces each; then per-filter sums ----
             {
-                const int fr = tid & 3, slot = tid >> 2;
-                const float* srow = slabs + fr * kSlab;
 #pragma unroll
                 for (int c = 0; c < kPieceRounds; ++c) {
-                    const int p = c * kPieceSlots + slot;
-                    const int k0 = pk0[p];
-                    const float4 w0 = *reinterpret_cast<const float4*>(pw + p * kPieceLen);
-                    const float4 w1 = *reinterpret_cast<const float4*>(pw + p * kPieceLen + 4);
-                    const float* s = srow + k0;
-                    float acc = w0.x * s[0];
-                    acc = fmaf(w0.y, s[1], acc);
-                    acc = fmaf(w0.z, s[2], acc);
-                    acc = fmaf(w0.w, s[3], acc);
-                    acc = fmaf(w1.x, s[4], acc);
-                    acc = fmaf(w1.y, s[5], acc);
-                    acc = fmaf(w1.z, s[6], acc);
-                    acc = fmaf(w1.w, s[7], acc);
-                    partial[p * 4 + fr] = acc;
+                    const int p = c * kPieceSlots + lane;
+                    const int info = pinfo[p];
+                    const float4 w0 = pw4[p], w1 = pw4[kPieces + p];
+                    const float4* s4 = reinterpret_cast<const float4*>(slab + (info & 0xffff));
+                    const float4 s0 = s4[0], s1 = s4[1];
+                    float acc = w0.x * s0.x;
+                    acc = fmaf(w0.y, s0.y, acc);
+                    acc = fmaf(w0.z, s0.z, acc);
+                    acc = fmaf(w0.w, s0.w, acc);
+                    acc = fmaf(w1.x, s1.x, acc);
+                    acc = fmaf(w1.y, s1.y, acc);
+                    acc = fmaf(w1.z, s1.z, acc);
+                    acc = fmaf(w1.w, s1.w, acc);
+                    partial[info >> 16] = acc;
+                }
+                lds_order();
+                // per-filter sums in fixed order; all (<= 10) partials are fetched before the first add so that the
+                // LDS latency is paid once, not per term
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int f = lane + 64 * pass;
+                    const int p0 = pass ? my_p0b : my_p0a, cnt = pass ? my_cntb : my_cnta;
+                    if (f < kMels) {
+                        float v[10];
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) v[q] = partial[p0 + (q < cnt ? q : 0)];
+                        float acc = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) acc += (q < cnt) ? v[q] : 0.f;
+                        mel[f * kMelStride + frame] = acc;
+                    }
                 }
             }
-            __syncthreads();   // (B) partials complete; slabs free for the next round's FFT
-            for (int idx = tid; idx < kMels * 4; idx += kThreads) {
-                const int f = idx >> 2, fr = idx & 3;
-                const int p0 = fp0[f], cnt = fcnt[f];
-                float acc = 0.f;
-                for (int q = 0; q < cnt; ++q) acc += partial[(p0 + q) * 4 + fr];
-                mel[f * kMelStride + round * 4 + fr] = acc;
-            }
+            lds_order();   // the slab and `partial` are rewritten by the next frame
         }
-        __syncthreads();
+        __syncthreads();   // all 32 frames' mel bands are in LDS
 
         // ---- per-clip peak and mel max ----
         float mmax = 0.f;
@@ -313,9 +358,14 @@ int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_
     if (n_clips == 0) return WW_OK;
     const LogmelTables* tb = device_tables();
     if (!tb) return WW_EHIP;
-    const int64_t resident = int64_t(device_cu_count()) * 3;      // LDS admits 3 workgroups per CU
+    const int64_t resident = int64_t(device_cu_count()) * 2;      // LDS and VGPRs admit 2 workgroups per CU
     const int grid = int(n_clips < resident ? n_clips : resident);
     const size_t lds_bytes = sizeof(float) * kLdsFloats;
+    static bool lds_attr_set = false;   // just over 64 KiB of dynamic LDS: needs the opt-in once per process
+    if (!lds_attr_set) {
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        lds_attr_set = true;
+    }
     hipLaunchKernelGGL(logmel_kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
                        int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
     WW_HIP(hipGetLastError());

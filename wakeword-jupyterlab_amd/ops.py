@@ -233,6 +233,27 @@ def forward_pcm(pcm, packed, n_conv, normalize: bool = True):
     return torch.ops.wakeword_amd.forward_pcm(pcm, packed, n_conv, normalize)
 
 
+CONV_MATH = {"f32": 0, "f16x3": 1}
+
+
+def set_conv_math(mode: str) -> None:
+    """Arithmetic of the conv2 implicit GEMM, process-wide: 'f32' (exact fp32 MFMA) or 'f16x3' (each fp32 operand as
+    two f16 halves, three f16 MFMAs per product block, fp32 accumulate; ~2^-21 relative error, 3/16 the MFMA cycles)."""
+    if mode not in CONV_MATH:
+        raise ValueError(f"conv math {mode!r}: expected one of {sorted(CONV_MATH)}")
+    nat.check(nat.lib.ww_set_conv_math(CONV_MATH[mode]))
+
+
+def get_conv_math() -> str:
+    return {v: k for k, v in CONV_MATH.items()}[nat.lib.ww_get_conv_math()]
+
+
 def init() -> None:
     """Upload the front-end tables for the current device (needed before hipGraph capture)."""
     nat.check(nat.lib.ww_init())
+
+
+import os as _os  # noqa: E402
+
+if _os.environ.get("WW_CONV_MATH"):
+    set_conv_math(_os.environ["WW_CONV_MATH"])
