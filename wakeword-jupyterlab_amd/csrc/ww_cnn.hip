@@ -17,6 +17,8 @@
 //   conv1's 327 KB/clip output never exists in HBM;  bias+ReLU+pool are fused into the MFMA epilogue.
 //
 // Algorithmic flops per clip (T = 32): conv1 1,474,560 + conv2 94,371,840.
+#include <cstdlib>
+
 #include "ww_internal.h"
 
 namespace ww {
@@ -243,6 +245,117 @@ __device__ __forceinline__ void conv1_band_split(const float* __restrict__ melt,
     }
 }
 
+// Shared MFMA body of the split-precision kernels: 36 fragment steps it = (cb*3 + dx)*6 + q over 4 output rows,
+// software-pipelined one step ahead (ds_read_b128 of step it+1 is in flight under the MFMAs of step it).
+__device__ __forceinline__ void mfma_rows4_f16x3(const char* __restrict__ ap, const half8 (&bh)[18], const half8 (&bl)[18],
+                                                 f32x16 (&acc)[4]) {
+    auto frag = [&](int it, int half) -> half8 {
+        const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
+        return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + dx) * kPosBytes + cb * 32 + half * 64));
+    };
+    half8 ah = frag(0, 0), al = frag(0, 1);
+#pragma unroll
+    for (int it = 0; it < 36; ++it) {
+        half8 ahn = ah, aln = al;
+        if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
+        const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int r = q - dy;
+            if (r < 0 || r > 3) continue;
+            const int ks = (cb * 3 + dx) * 3 + dy;
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[r], 0, 0, 0);
+        }
+        ah = ahn; al = aln;
+    }
+}
+
+// 2*relu(v) = v + |v| : one VALU op, exact, NaN-propagating (the factor 2 is folded into the pool scale)
+__device__ __forceinline__ float relu2(float v) { return v + __builtin_fabsf(v); }
+
+// ------------------------------------------------------------------------------------------------
+// SYMMETRIC variant: 4 waves per workgroup, 2 workgroups per CU, every wave alternates conv1 (VALU) and its MFMA
+// tile per band.  The second workgroup of a CU starts half a band late so that its VALU phase falls under the
+// other's MFMA phase (two identical workgroups otherwise run in lockstep and serialise both phases).
+// ------------------------------------------------------------------------------------------------
+constexpr int kC2hsLdsBytes = kHActBytes + kMelFloats * 4 + 4 * 32 * 4;
+
+__global__ __launch_bounds__(256, 2) void cnn2hs_kernel(const float* __restrict__ mel, int n, int width,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const u32x4* __restrict__ wH, const float* __restrict__ hs,
+                                                        const float* __restrict__ b2, float* __restrict__ out,
+                                                        int stagger_from, int stagger_sleeps) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* act = ldsb;
+    float* melt = reinterpret_cast<float*>(ldsb + kHActBytes);
+    float* red = melt + kMelFloats;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1, rg = wave >> 1;
+    const int x = lane & 31, h = lane >> 5;
+
+    half8 bh[18], bl[18];
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+        bh[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 0) * 64 + lane]);
+        bl[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 1) * 64 + lane]);
+    }
+    const float bias = b2[32 * nt + x];
+    const float descale = hs[0];
+    for (int i = tid; i < kC2hsLdsBytes / 4; i += 256) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
+    const char* ap = act + ((rg * 4) * kRS + x) * kPosBytes + h * 16;
+    const float half_inv_area = 0.5f / float(kH * width);
+    if (int(blockIdx.x) >= stagger_from)
+        for (int i = 0; i < stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);      // 127 * 64 cycles each
+
+    for (int clip = blockIdx.x; clip < n; clip += gridDim.x) {
+        __syncthreads();
+        const float* __restrict__ src = mel + int64_t(clip) * kH * width;
+        for (int i = tid; i < kH * width; i += 256) {
+            const int y = i / width, xx = i - y * width;
+            melt[(y + 1) * kMelRS + xx + 1] = src[i];
+        }
+        float pool = 0.f;
+        for (int band = 0; band < kH / kBand; ++band) {
+            __syncthreads();
+            conv1_band_split(melt, act, w1, b1, band * kBand, width, wave, lane);
+            __syncthreads();
+            f32x16 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+            mfma_rows4_f16x3(ap, bh, bl, acc);
+            if (width == kW) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) pool += relu2(fmaf(acc[r][j], descale, bias));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
+                        const float v = relu2(fmaf(acc[r][j], descale, bias));
+                        pool += (col < width) ? v : 0.f;
+                    }
+            }
+        }
+        pool += __shfl_xor(pool, 32);
+        __syncthreads();
+        if (lane < 32) red[wave * 32 + lane] = pool;
+        __syncthreads();
+        if (tid < 64) {
+            const int t_nt = tid >> 5, t_x = tid & 31;
+            out[int64_t(clip) * 64 + tid] = (red[t_nt * 32 + t_x] + red[(2 + t_nt) * 32 + t_x]) * half_inv_area;
+        }
+    }
+}
+
 // Workgroup = 8 waves with fixed roles, one workgroup per CU (persistent over clips):
 //   waves 0-3  CONSUMERS: (row group, N-tile) MFMA tiles of the current band + bias/ReLU/pool epilogue
 //   waves 4-7  PRODUCERS: conv1 of the NEXT band on the VALU into the other half of a double-buffered LDS tile,
@@ -402,6 +515,264 @@ __global__ __launch_bounds__(512, 2) void cnn2h_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// 16x16x32 variant of the split-precision kernel: 12 waves per workgroup (one per CU, 3 waves per SIMD, <= 168 VGPRs):
+//   waves 0-7   CONSUMERS = (row group of 4 rows) x (N-tile of 16 channels): 72 B-operand VGPRs each, so TWO matrix-pipe
+//               waves share every SIMD and hide each other's LDS latency (one 250-VGPR wave per SIMD cannot)
+//   waves 8-11  PRODUCERS: conv1 of the next band (VALU) into the other half of the double-buffered tile
+// Position record = 160 bytes ([32 ci hi][32 ci lo][32 B pad]): conflict-free for the 16x16x32 A-fragment reads
+// (lane = (position i, channel quarter kq) reads 16 B at position*160 + kq*16).
+// ------------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kPos16 = 160;
+constexpr int kH16Row = kRS * kPos16;
+constexpr int kH16Act = kARows * kH16Row;                   // 54,400 B per buffer
+constexpr int kC2h16Lds = 2 * kH16Act + 4 * ((kH + 2) * 36) * 2 + 8 * 16 * 4;
+
+__device__ __forceinline__ void conv1_band_split16(const float* __restrict__ melt, char* __restrict__ act,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1, int y0,
+                                                   int width, int pw, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int i = 0; i < kARows / 2; ++i) {
+        const int q = 2 * i + h;
+        const int y = y0 - 1 + q;
+        const bool inside = (y >= 0) && (y < kH) && (x < width);
+        const float* m = melt + (inside ? y : 0) * kMelRS + x;
+        const float m00 = m[0], m01 = m[1], m02 = m[2];
+        const float m10 = m[kMelRS], m11 = m[kMelRS + 1], m12 = m[kMelRS + 2];
+        const float m20 = m[2 * kMelRS], m21 = m[2 * kMelRS + 1], m22 = m[2 * kMelRS + 2];
+        _Float16 hi[8], lo[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ci = 8 * pw + u;
+            const float* w = w1 + ci * 9;
+            float v = b1[ci];
+            v = fmaf(w[0], m00, v); v = fmaf(w[1], m01, v); v = fmaf(w[2], m02, v);
+            v = fmaf(w[3], m10, v); v = fmaf(w[4], m11, v); v = fmaf(w[5], m12, v);
+            v = fmaf(w[6], m20, v); v = fmaf(w[7], m21, v); v = fmaf(w[8], m22, v);
+            v = inside ? relu(v) : 0.f;
+            hi[u] = static_cast<_Float16>(v);
+            lo[u] = static_cast<_Float16>(v - static_cast<float>(hi[u]));
+        }
+        char* rec = act + (q * kRS + x + 1) * kPos16 + pw * 16;
+        u32x4 vh, vl;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { vh[d] = pack_h2(hi[2 * d], hi[2 * d + 1]); vl[d] = pack_h2(lo[2 * d], lo[2 * d + 1]); }
+        *reinterpret_cast<u32x4*>(rec) = vh;
+        *reinterpret_cast<u32x4*>(rec + 64) = vl;
+    }
+}
+
+// conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
+//   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
+// The log-mel tile is kept as two f16 planes (hi, lo) so the patch operand needs no conversions.  The result lands
+// with the column on the lane and 16 channels in registers: 2*relu, split, 8-byte stores into the position records.
+constexpr int kMelHRS = 36;                              // f16 plane row stride (columns -1..34)
+constexpr int kMelHPlane = (kH + 2) * kMelHRS;           // halfs per plane
+__device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const _Float16* __restrict__ ml,
+                                                char* __restrict__ act, half8 a1h, half8 a1l, int y0, int width,
+                                                int pw, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int q = pw; q < kARows; q += 4) {
+        const int y = y0 - 1 + q;
+        char* rec = act + (q * kRS + x + 1) * kPos16 + h * 8;        // channels 4h.. of each group of 8
+        if (y < 0 || y >= kH) {                                        // outside the image: conv2's zero padding
+#pragma unroll
+            for (int gch = 0; gch < 4; ++gch) {
+                *reinterpret_cast<uint2*>(rec + gch * 16) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(rec + 64 + gch * 16) = make_uint2(0u, 0u);
+            }
+            continue;
+        }
+        // patch operand B[k = 8h + j][x]: taps 0..7 on the lower half-wave; tap 8, the bias tap (1.0) and zeros on the upper
+        half8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = j;                                           // tap index for h == 0
+            const int dy = k / 3, dx = k % 3;
+            const int o0 = (y + dy) * kMelHRS + x + dx;                // tile coords: row y+dy-1 -> y+dy, col x+dx-1 -> x+dx
+            const int o1 = (y + 2) * kMelHRS + x + 2;                  // tap 8 (dy = 2, dx = 2)
+            const _Float16 one = static_cast<_Float16>(1.0f), zero = static_cast<_Float16>(0.0f);
+            const _Float16 vh0 = mh[o0], vl0 = ml[o0];
+            if (j == 0) {
+                const _Float16 vh1 = mh[o1], vl1 = ml[o1];
+                ph[j] = h ? vh1 : vh0;
+                pl[j] = h ? vl1 : vl0;
+            } else if (j == 1) {
+                ph[j] = h ? one : vh0;
+                pl[j] = h ? zero : vl0;
+            } else {
+                ph[j] = h ? zero : vh0;
+                pl[j] = h ? zero : vl0;
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, ph, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, pl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, ph, acc, 0, 0, 0);
+        // D: lane&31 = column x, register j <-> channel (j&3) + 8*(j>>2) + 4*h
+        const bool col_ok = x < width;
+#pragma unroll
+        for (int gch = 0; gch < 4; ++gch) {
+            _Float16 hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = relu2(acc[4 * gch + e]);                     // 2*relu: the factor is folded into conv2's descale
+                t = col_ok ? t : 0.f;
+                hi[e] = static_cast<_Float16>(t);
+                lo[e] = static_cast<_Float16>(t - static_cast<float>(hi[e]));
+            }
+            *reinterpret_cast<uint2*>(rec + gch * 16) = make_uint2(pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]));
+            *reinterpret_cast<uint2*>(rec + 64 + gch * 16) = make_uint2(pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict__ mel, int n, int width,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const u32x4* __restrict__ w1H,
+                                                         const u32x4* __restrict__ wH, const float* __restrict__ hs,
+                                                         const float* __restrict__ b2, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* act0 = ldsb;
+    _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + 2 * kH16Act);       // 2 clips x (hi plane, lo plane) of [82][36] f16
+    float* red = reinterpret_cast<float*>(melh0 + 4 * kMelHPlane);           // [8 consumer waves][16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 8;
+    const int nt = wave & 3, rg = (wave >> 2) & 1;
+    const int pi = lane & 15, kq = lane >> 4;
+    const int ptid = tid - 512;
+
+    half8 bh[9], bl[9];
+    float bias = 0.f, descale = 0.f;
+    if (consumer) {
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+            bh[ks] = __builtin_bit_cast(half8, wH[((nt * 9 + ks) * 2 + 0) * 64 + lane]);
+            bl[ks] = __builtin_bit_cast(half8, wH[((nt * 9 + ks) * 2 + 1) * 64 + lane]);
+        }
+        bias = b2[16 * nt + pi];
+        descale = 0.5f * hs[0];                  // conv1 activations are stored as 2*relu(.)
+    }
+    half8 a1h = {}, a1l = {};
+    if (!consumer) {
+        a1h = __builtin_bit_cast(half8, w1H[lane]);
+        a1l = __builtin_bit_cast(half8, w1H[64 + lane]);
+    }
+    for (int i = tid; i < kC2h16Lds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
+    __syncthreads();
+
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int steps = my_clips * (kH / kBand);
+    const float half_inv_area = 0.5f / float(kH * width);
+
+    auto load_mel = [&](int k) {     // log-mel image -> two f16 planes (hi, lo) with a zero halo
+        const float* __restrict__ src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kH * width;
+        _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
+        _Float16* pl = ph + kMelHPlane;
+        for (int i = ptid; i < kH * width; i += 256) {
+            const int y = i / width, xx = i - y * width;
+            const float v = src[i];
+            const _Float16 hi = static_cast<_Float16>(v);
+            ph[(y + 1) * kMelHRS + xx + 1] = hi;
+            pl[(y + 1) * kMelHRS + xx + 1] = static_cast<_Float16>(v - static_cast<float>(hi));
+        }
+    };
+    auto produce = [&](int g) {
+        const int k = g / (kH / kBand), band = g - k * (kH / kBand);
+        const _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
+        conv1_rows_mfma(ph, ph + kMelHPlane, act0 + (g & 1) * kH16Act, a1h, a1l, band * kBand, width, wave - 8, lane);
+    };
+    auto write_pooled = [&](int k) {     // wave 0: pooled[clip][co], co = lane: sum the two row groups
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const int t_nt = lane >> 4, t_n = lane & 15;
+        out[clip * 64 + lane] = (red[t_nt * 16 + t_n] + red[(4 + t_nt) * 16 + t_n]) * half_inv_area;
+    };
+
+    if (!consumer && steps > 0) load_mel(0);
+    __syncthreads();
+    if (!consumer && steps > 0) {
+        produce(0);
+        if (my_clips > 1) load_mel(1);
+    }
+    __syncthreads();
+
+    float pool = 0.f;
+    for (int g = 0; g < steps; ++g) {
+        const int k = g / (kH / kBand), band = g - k * (kH / kBand);
+        if (consumer) {
+            if (band == 0 && g > 0 && wave == 0) write_pooled(k - 1);
+            const char* ap = act0 + (g & 1) * kH16Act + ((rg * 4) * kRS + pi) * kPos16 + kq * 16;
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[r][c][j] = 0.f;
+            // 36 fragment steps it = (dx*6 + q)*2 + ch, pipelined one step ahead
+            auto frag = [&](int it, int half) -> half8 {
+                const int dx = it / 12, q = (it / 2) % 6, ch = it & 1;
+                return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + 16 * ch + dx) * kPos16 + half * 64));
+            };
+            half8 ah = frag(0, 0), al = frag(0, 1);
+#pragma unroll
+            for (int it = 0; it < 36; ++it) {
+                half8 ahn = ah, aln = al;
+                if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
+                const int dx = it / 12, q = (it / 2) % 6, ch = it & 1;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = q - dy;
+                    if (r < 0 || r > 3) continue;
+                    const int ks = dx * 3 + dy;
+                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc[r][ch], 0, 0, 0);
+                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[r][ch], 0, 0, 0);
+                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[r][ch], 0, 0, 0);
+                }
+                ah = ahn; al = aln;
+            }
+            // D layout 16x16: lane&15 = channel, register j <-> position 16*ch + 4*(lane>>4) + j
+            if (band == 0) pool = 0.f;
+            if (width == kW) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pool += relu2(fmaf(acc[r][c][j], descale, bias));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = relu2(fmaf(acc[r][c][j], descale, bias));
+                            pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
+                        }
+            }
+            if (band == kH / kBand - 1) {
+                float p2 = pool + __shfl_xor(pool, 16);
+                p2 += __shfl_xor(p2, 32);
+                if (lane < 16) red[wave * 16 + lane] = p2;
+            }
+        } else if (g + 1 < steps) {
+            produce(g + 1);
+            const int k1 = (g + 1) / (kH / kBand);
+            if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);
+        }
+        __syncthreads();
+    }
+    if (consumer && wave == 0 && steps > 0) write_pooled(my_clips - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv3 (64->128) + ReLU + pool for the 3-conv WakewordModel.  512 threads: wave = (K-half kh, N-tile nt);
 // the two K-halves of an N-tile are summed through LDS before bias/ReLU.  Band = 4 output rows.
 // in = relu(conv2) as [n][80][64][32]; out = pooled [n][128].
@@ -500,6 +871,34 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
         h_attr_set = true;
     }
     const u32x4* wH = reinterpret_cast<const u32x4*>(packed + L.conv2_h);
+    // WW_CNN_STRUCT: "n16" (default) 12-wave 16x16x32 kernel; "sym" 4-wave symmetric; "spec" 8-wave 32x32x16 roles
+    static const int h_struct = [] {
+        const char* e = getenv("WW_CNN_STRUCT");
+        if (!e) return 2;
+        return e[0] == 'n' ? 2 : (e[0] == 's' && e[1] == 'p') ? 1 : 0;
+    }();
+    if (n_conv == 2 && split && h_struct == 2) {
+        static bool a16 = false;
+        if (!a16) {
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
+            a16 = true;
+        }
+        hipLaunchKernelGGL(cnn2h16_kernel, dim3(grid_h), dim3(768), kC2h16Lds, stream, mel, int(n), width,
+                           packed + L.conv1_w, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv1_h),
+                           reinterpret_cast<const u32x4*>(packed + L.conv2_h16),
+                           packed + L.conv2_hs, packed + L.conv2_b, pooled);
+        WW_HIP(hipGetLastError());
+        return WW_OK;
+    }
+    static const int h_sleeps = [] { const char* e = getenv("WW_CNN_STAGGER"); return e ? atoi(e) : 1; }();
+    if (n_conv == 2 && split && h_struct == 0) {
+        const int cus = device_cu_count();
+        hipLaunchKernelGGL(cnn2hs_kernel, dim3(grid), dim3(256), kC2hsLdsBytes, stream, mel, int(n), width,
+                           packed + L.conv1_w, packed + L.conv1_b, wH, packed + L.conv2_hs, packed + L.conv2_b, pooled,
+                           cus, h_sleeps);
+        WW_HIP(hipGetLastError());
+        return WW_OK;
+    }
     if (n_conv == 2 && split) {
         hipLaunchKernelGGL(cnn2h_kernel<true>, dim3(grid_h), dim3(512), kC2hLdsBytes2, stream, mel, int(n), width,
                            packed + L.conv1_w, packed + L.conv1_b, wH, packed + L.conv2_hs, packed + L.conv2_b, pooled);

@@ -79,6 +79,8 @@ struct PackedLayout {
     // split-precision image of conv2 for the f16x3 kernel: W * 2^S = hi + lo (two f16), MFMA 32x32x16 B-operand order
     int64_t conv2_h;   // [2 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64 lanes][4 dwords = 8 f16]
     int64_t conv2_hs;  // [4]: 2^-S (descale applied to the f32 accumulator), S, 0, 0
+    int64_t conv1_h;   // conv1 as a 32x32x16 f16 MFMA A operand: [hi,lo][64 lanes][4 dwords]; k = tap 0..8, k = 9: bias
+    int64_t conv2_h16; // same weights for v_mfma_f32_16x16x32_f16: [4 ntile][9 kstep = dx*3+dy][hi,lo][64 lanes][4 dwords]
     int64_t total;
 };
 PackedLayout packed_layout(int n_conv);

@@ -100,23 +100,45 @@ __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float4 load_samples(const float* __restrict__ clip, int idx, int clip_len,
-                                               const int32_t* ring_pos_p, int ring_pos, int ring_len) {
-    // idx is a multiple of 4; [idx, idx+4) lies wholly before 0, wholly inside, or straddles clip_len
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx >= 0 && idx < clip_len) {
-        int at = idx;
-        if (ring_pos_p) { at = idx + ring_pos; if (at >= ring_len) at -= ring_len; }
-        if (idx + 4 <= clip_len) {
-            x = *reinterpret_cast<const float4*>(clip + at);
+// Eight float4 loads of one frame (samples base + 256*n1 .. +3).  ALIGNED (clip_len % 4 == 0, which includes the
+// 16000-sample case and the streaming ring): every float4 is wholly inside or wholly outside the clip, so the loads
+// are branch-free -- clamped address + select -- and all eight stay in flight together.  Otherwise a float4 can
+// straddle clip_len and the tail is fetched element-wise (rare: ragged clip lengths).
+template <bool ALIGNED>
+__device__ __forceinline__ void load_frame(float4 (&sn)[8], const float* __restrict__ clip, int base, int clip_len,
+                                           bool ring, int ring_pos, int ring_len) {
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int idx = base + 256 * n1;              // multiple of 4
+        if constexpr (ALIGNED) {
+            const bool ok = idx >= 0 && idx < clip_len;
+            int at = ok ? idx : 0;
+            if (ring) { at += ring_pos; at = at >= ring_len ? at - ring_len : at; }
+            const float4 v = *reinterpret_cast<const float4*>(clip + at);
+            sn[n1] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            x.x = clip[at];
-            if (idx + 1 < clip_len) x.y = clip[at + 1];
-            if (idx + 2 < clip_len) x.z = clip[at + 2];
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx >= 0 && idx < clip_len) {
+                if (idx + 4 <= clip_len) {
+                    x = *reinterpret_cast<const float4*>(clip + idx);
+                } else {
+                    x.x = clip[idx];
+                    if (idx + 1 < clip_len) x.y = clip[idx + 1];
+                    if (idx + 2 < clip_len) x.z = clip[idx + 2];
+                }
+            }
+            sn[n1] = x;
         }
     }
-    return x;
 }
+
+#ifdef WW_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+    if (stamp_on) { acc_st[i] += t__ - last_st; } last_st = t__; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
                                                              int clip_len, int n_clips, int normalize,
@@ -155,6 +177,8 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     for (int i = tid; i < 7 * 128 * 2; i += kThreads) lds[kOffTw1 + i] = (&tb->tw1[0][0].x)[i];
     for (int i = tid; i < kNfft; i += kThreads) lds[kOffWin + i] = tb->window[i];
     const int ring_pos = ring_pos_p ? *ring_pos_p : 0;
+    const bool ring = ring_pos_p != nullptr;
+    const bool aligned = (clip_len & 3) == 0;        // uniform: picks the branch-free frame loads
     __syncthreads();
     // this lane's filters in the per-frame combine: f = lane and f = lane + 64 (< 80)
     const int my_p0a = fp0[lane], my_cnta = fcnt[lane];
@@ -166,6 +190,11 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     //   X2: u[reader lane][m] at reader*8 + (m ^ ((reader>>1)&7)),  reader = 8*k1 + k2, m = n''/2
     //   Z : Z[k]              at float2 index k ^ (((k>>4)&3) << 1)
     const int k1r = lane >> 3, jr = lane & 7;                   // pass-2 role: (k1, j)
+#ifdef WW_STAMPS
+    const bool stamp_on = true;
+    unsigned long long acc_st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_st = 0;
+    STAMP(9);
+#endif
 
 #pragma unroll 1
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
@@ -173,15 +202,15 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
         float peak = 0.f;
         // the samples of a frame are fetched one frame ahead (8 x dwordx4 per lane in flight under the FFT)
         float4 sn[8];
-#pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1)
-            sn[n1] = load_samples(x, wave * kHop - kNfft / 2 + 4 * lane + 256 * n1, clip_len, ring_pos_p, ring_pos, ring_len);
+        if (aligned) load_frame<true>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len);
+        else load_frame<false>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len);
 
 #pragma unroll 1
         for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
             const int frame = round * kWavesPerBlock + wave;
             const int base_next = (frame + kWavesPerBlock) * kHop - kNfft / 2 + 4 * lane;
 
+            STAMP(8);
             // ---- load + window: lane holds z[128 n1 + 2 lane + q], q = 0,1, n1 = 0..7 ----
             float2 za[8], zb[8];
 #pragma unroll
@@ -191,11 +220,6 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
                 za[n1] = make_float2(s.x * w.x, s.y * w.y);
                 zb[n1] = make_float2(s.z * w.z, s.w * w.w);
-            }
-            if (round + 1 < kFrames / kWavesPerBlock) {
-#pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1)
-                    sn[n1] = load_samples(x, base_next + 256 * n1, clip_len, ring_pos_p, ring_pos, ring_len);
             }
             // ---- pass 1: radix 8 over n1 (stride 128), twiddle W_1024^{n' k1}, store X1 ----
             dft8(za);
@@ -209,6 +233,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 slab4[k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)))] = make_float4(a.x, a.y, b.x, b.y);
             }
             lds_order();
+            STAMP(0);
             // ---- pass 2: lane = (k1, j): radix 8 over n2 of y[k1][16 n2 + 2j + q]; twiddle W_128; store X2 ----
             {
                 const int sw1 = 8 * ((k1r >> 1) & 1);
@@ -234,6 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 }
             }
             lds_order();
+            STAMP(1);
             // ---- pass 3: lane = (k1, k2): radix 16 over n'' -> Z[k1 + 8 k2 + 64 k''] ----
             {
                 float2 u[16];
@@ -254,6 +280,13 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 }
             }
             lds_order();
+            STAMP(2);
+            // next frame's samples: issued here, after the register-hungry FFT passes, and in flight under the
+            // power / mel stages (about a third of the frame time, several times the HBM latency)
+            if (round + 1 < kFrames / kWavesPerBlock) {
+                if (aligned) load_frame<true>(sn, x, base_next, clip_len, ring, ring_pos, ring_len);
+                else load_frame<false>(sn, x, base_next, clip_len, ring, ring_pos, ring_len);
+            }
             // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
             {
                 float2 a[8], b[8];
@@ -279,6 +312,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 if (lane == 0) slab[0] = 0.f;     // bin 0 carries zero mel weight but is read by window 0
             }
             lds_order();
+            STAMP(3);
             // ---- sparse mel of THIS wave's frame: lane = slot, 5 pieces each; then per-filter sums ----
             {
 #pragma unroll
@@ -299,6 +333,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                     partial[info >> 16] = acc;
                 }
                 lds_order();
+                STAMP(4);
                 // per-filter sums in fixed order; all (<= 10) partials are fetched before the first add so that the
                 // LDS latency is paid once, not per term
 #pragma unroll
@@ -317,8 +352,10 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
                 }
             }
             lds_order();   // the slab and `partial` are rewritten by the next frame
+            STAMP(5);
         }
         __syncthreads();   // all 32 frames' mel bands are in LDS
+        STAMP(6);
 
         // ---- per-clip peak and mel max ----
         float mmax = 0.f;
@@ -350,8 +387,21 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             o[idx] = db;
         }
         __syncthreads();   // mel / red are rewritten by the next clip
+        STAMP(7);
     }
+#ifdef WW_STAMPS
+    if (lane == 0 && wave == 1 && blockIdx.x == 7)
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], acc_st[i]);
+#endif
 }
+#ifdef WW_STAMPS
+extern "C" __attribute__((visibility("default"))) int ww_debug_stamps(unsigned long long* out) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(z)) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    return 0;
+}
+#endif
 
 int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
                   const int32_t* ring_pos, int64_t ring_len, float* logmel, hipStream_t stream) {

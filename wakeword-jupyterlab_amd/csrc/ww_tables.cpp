@@ -137,6 +137,8 @@ PackedLayout packed_layout(int n_conv) {
     L.fc_b = take(4);
     L.conv2_h = take(2 * 18 * 2 * 64 * 4);
     L.conv2_hs = take(4);
+    L.conv1_h = take(2 * 64 * 4);
+    L.conv2_h16 = take(4 * 9 * 2 * 64 * 4);
     L.total = o;
     return L;
 }
@@ -159,7 +161,7 @@ static void pack_conv_b_operand(const float* w, int cout, int cin, float* out) {
 // W' = W * 2^S (S chosen so that max|W'| lies in [2^12, 2^13): both halves stay normal f16), W' ~= hi + lo.
 // k-step ks = (cb*3 + dx)*3 + dy covers input channels 16*cb .. 16*cb+15 of tap (dy, dx); lane (n = lane&31,
 // h = lane>>5) holds B[k = 8h + j][n] = W'[32*nt + n][16*cb + 8h + j][dy][dx], j = 0..7, as 4 dwords.
-static float pack_conv2_f16x3(const float* w, float* out_words) {
+static float pack_conv2_f16x3(const float* w, float* out_words, float* out_words16) {
     float wmax = 0.f;
     for (int i = 0; i < 64 * 32 * 9; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
     int S = 0;
@@ -187,7 +189,46 @@ static float pack_conv2_f16x3(const float* w, float* out_words) {
                             o16[base + 64 * 8 + lane * 8 + j] = lb;
                         }
                 }
+    // second image, for the 16x16x32 tiles: k-step ks = dx*3 + dy covers all 32 input channels of a tap; lane
+    // (n = lane&15, kq = lane>>4) holds B[k = 8kq + j][n] = W'[16*nt + n][8kq + j][dy][dx], j = 0..7
+    uint16_t* o16b = reinterpret_cast<uint16_t*>(out_words16);
+    for (int nt = 0; nt < 4; ++nt)
+        for (int dx = 0; dx < 3; ++dx)
+            for (int dy = 0; dy < 3; ++dy) {
+                const int ks = dx * 3 + dy;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 16 * nt + (lane & 15), ci = 8 * (lane >> 4) + j;
+                        const float v = w[((co * 32 + ci) * 3 + dy) * 3 + dx] * scale;
+                        const _Float16 hi = static_cast<_Float16>(v);
+                        const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
+                        uint16_t hb, lb;
+                        std::memcpy(&hb, &hi, 2);
+                        std::memcpy(&lb, &lo, 2);
+                        const int64_t base = ((int64_t(nt) * 9 + ks) * 2) * 64 * 8;
+                        o16b[base + lane * 8 + j] = hb;
+                        o16b[base + 64 * 8 + lane * 8 + j] = lb;
+                    }
+            }
     return std::ldexp(1.0f, -S);
+}
+
+// conv1 weight [32][1][3][3] + bias as the A operand of v_mfma_f32_32x32x16_f16 (M = channel, K = 9 taps + bias tap):
+// lane (m = lane&31, h = lane>>5) holds A[m][k = 8h + j]: k < 9 -> w1[m][k], k == 9 -> b1[m] (its patch value is 1.0), else 0.
+static void pack_conv1_f16x3(const float* w, const float* b, float* out_words) {
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+            const int m = lane & 31, k = 8 * (lane >> 5) + j;
+            const float v = k < 9 ? w[m * 9 + k] : (k == 9 ? b[m] : 0.0f);
+            const _Float16 hi = static_cast<_Float16>(v);
+            const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
+            uint16_t hb, lb;
+            std::memcpy(&hb, &hi, 2);
+            std::memcpy(&lb, &lo, 2);
+            o16[lane * 8 + j] = hb;
+            o16[64 * 8 + lane * 8 + j] = lb;
+        }
 }
 
 // weight_ih [4H][K] (gate rows i,f,g,o) -> [K][768], column (hb*3 + gate)*32 + u  <-  row goff[gate] + 32*hb + u
@@ -255,7 +296,8 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     pack_lstm(sd->lstm_weight_ih[1], sd->lstm_bias_ih[1], sd->lstm_bias_hh[1], kHidden, out + L.l1_w, out + L.l1_b);
     std::memcpy(out + L.fc_w, sd->fc_weight, sizeof(float) * 2 * kHidden);
     std::memcpy(out + L.fc_b, sd->fc_bias, sizeof(float) * 2);
-    out[L.conv2_hs] = pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h);
+    pack_conv1_f16x3(sd->conv_weight[0], sd->conv_bias[0], out + L.conv1_h);
+    out[L.conv2_hs] = pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h, out + L.conv2_h16);
     return WW_OK;
 }
 
