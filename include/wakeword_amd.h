@@ -67,7 +67,7 @@ WW_API int ww_init(void);
 /* Device facts used by bench.py for the roofline denominator: number of CUs, max clock (kHz). */
 WW_API int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len);
 
-/* Arithmetic of the conv2 implicit GEMM (94 of the model's 96.5 MFLOP per clip); process-wide, default F32.
+/* Arithmetic of the conv2 implicit GEMM (94 of the model's 96.5 MFLOP per clip); process-wide, default F16X3.
  *   WW_CONV_MATH_F32    v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (an fmaf chain)
  *   WW_CONV_MATH_F16X3  each fp32 operand carried as two f16 halves (22 significant bits), every product block as
  *                       three v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative error per product

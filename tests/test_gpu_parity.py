@@ -27,6 +27,14 @@ def ops():
     return o
 
 
+@pytest.fixture(params=["f16x3", "f32"], autouse=True)
+def conv_math(request, ops):
+    """Every test runs under both conv2 arithmetics: the default split-precision f16x3 kernels and the exact-f32 MFMA one."""
+    ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math("f16x3")
+
+
 @pytest.fixture(scope="module")
 def clips64():
     return pkg.synth.make_clips(0, 64)          # BASELINE config 1: 64 synthetic 1 s clips

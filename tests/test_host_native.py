@@ -82,6 +82,25 @@ def test_packed_weight_image_layout(arch):
             assert np.array_equal(b[:, g, :].reshape(-1), bias[rows])
     assert np.array_equal(take(512), sd["fc.weight"].reshape(-1))
     assert np.array_equal(take(4)[:2], sd["fc.bias"])
+    # split-precision images: w * 2^S = hi + lo (two f16 halves), good to ~2^-21 of the layer's largest weight
+    w2 = sd["conv2.weight"].astype(np.float64)
+    h32 = take(2 * 18 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(2, 18, 2, 64, 8)     # [nt][ks][hi/lo][lane][j]
+    descale = float(take(4)[0])
+    S = -int(round(np.log2(descale)))
+    assert 2.0 ** 12 <= np.abs(w2).max() * 2.0 ** S < 2.0 ** 13
+    nt, cb, dx, dy, lane, j = np.meshgrid(np.arange(2), np.arange(2), np.arange(3), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
+    want = w2[32 * nt + (lane & 31), 16 * cb + 8 * (lane >> 5) + j, dy, dx] * 2.0 ** S
+    got = (h32[:, :, 0] + h32[:, :, 1]).reshape(2, 2, 3, 3, 64, 8)                                   # ks = (cb*3 + dx)*3 + dy
+    assert np.abs(got - want).max() <= np.abs(want).max() * 2.0 ** -21
+    c1 = take(2 * 64 * 4).view(np.float16).astype(np.float64).reshape(2, 64, 8)                      # conv1 A operand: taps + bias tap
+    lane, j = np.meshgrid(np.arange(64), np.arange(8), indexing="ij")
+    k = 8 * (lane >> 5) + j
+    w1b = np.concatenate([sd["conv1.weight"].reshape(32, 9), sd["conv1.bias"][:, None], np.zeros((32, 6), np.float32)], 1).astype(np.float64)
+    assert np.abs((c1[0] + c1[1]) - w1b[lane & 31, k]).max() <= 2.0 ** -22
+    h16 = take(4 * 9 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(4, 9, 2, 64, 8)       # [nt16][ks = dx*3+dy][hi/lo][lane][j]
+    nt, dx, dy, lane, j = np.meshgrid(np.arange(4), np.arange(3), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
+    want16 = w2[16 * nt + (lane & 15), 8 * (lane >> 4) + j, dy, dx] * 2.0 ** S
+    assert np.abs((h16[:, :, 0] + h16[:, :, 1]).reshape(4, 3, 3, 64, 8) - want16).max() <= np.abs(want16).max() * 2.0 ** -21
     assert o == p.size
 
 

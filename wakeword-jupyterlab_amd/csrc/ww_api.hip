@@ -68,7 +68,7 @@ const LogmelTables* device_tables() {
     return devp;
 }
 
-static int g_conv_math = 0;
+static int g_conv_math = WW_CONV_MATH_F16X3;
 int conv_math_mode() { return g_conv_math; }
 void set_conv_math_mode(int mode) { g_conv_math = mode; }
 

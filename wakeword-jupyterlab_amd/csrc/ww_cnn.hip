@@ -275,87 +275,6 @@ __device__ __forceinline__ void mfma_rows4_f16x3(const char* __restrict__ ap, co
 // 2*relu(v) = v + |v| : one VALU op, exact, NaN-propagating (the factor 2 is folded into the pool scale)
 __device__ __forceinline__ float relu2(float v) { return v + __builtin_fabsf(v); }
 
-// ------------------------------------------------------------------------------------------------
-// SYMMETRIC variant: 4 waves per workgroup, 2 workgroups per CU, every wave alternates conv1 (VALU) and its MFMA
-// tile per band.  The second workgroup of a CU starts half a band late so that its VALU phase falls under the
-// other's MFMA phase (two identical workgroups otherwise run in lockstep and serialise both phases).
-// ------------------------------------------------------------------------------------------------
-constexpr int kC2hsLdsBytes = kHActBytes + kMelFloats * 4 + 4 * 32 * 4;
-
-__global__ __launch_bounds__(256, 2) void cnn2hs_kernel(const float* __restrict__ mel, int n, int width,
-                                                        const float* __restrict__ w1, const float* __restrict__ b1,
-                                                        const u32x4* __restrict__ wH, const float* __restrict__ hs,
-                                                        const float* __restrict__ b2, float* __restrict__ out,
-                                                        int stagger_from, int stagger_sleeps) {
-    extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    char* act = ldsb;
-    float* melt = reinterpret_cast<float*>(ldsb + kHActBytes);
-    float* red = melt + kMelFloats;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = wave & 1, rg = wave >> 1;
-    const int x = lane & 31, h = lane >> 5;
-
-    half8 bh[18], bl[18];
-#pragma unroll
-    for (int ks = 0; ks < 18; ++ks) {
-        bh[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 0) * 64 + lane]);
-        bl[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 1) * 64 + lane]);
-    }
-    const float bias = b2[32 * nt + x];
-    const float descale = hs[0];
-    for (int i = tid; i < kC2hsLdsBytes / 4; i += 256) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
-    const char* ap = act + ((rg * 4) * kRS + x) * kPosBytes + h * 16;
-    const float half_inv_area = 0.5f / float(kH * width);
-    if (int(blockIdx.x) >= stagger_from)
-        for (int i = 0; i < stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);      // 127 * 64 cycles each
-
-    for (int clip = blockIdx.x; clip < n; clip += gridDim.x) {
-        __syncthreads();
-        const float* __restrict__ src = mel + int64_t(clip) * kH * width;
-        for (int i = tid; i < kH * width; i += 256) {
-            const int y = i / width, xx = i - y * width;
-            melt[(y + 1) * kMelRS + xx + 1] = src[i];
-        }
-        float pool = 0.f;
-        for (int band = 0; band < kH / kBand; ++band) {
-            __syncthreads();
-            conv1_band_split(melt, act, w1, b1, band * kBand, width, wave, lane);
-            __syncthreads();
-            f32x16 acc[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
-            mfma_rows4_f16x3(ap, bh, bl, acc);
-            if (width == kW) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) pool += relu2(fmaf(acc[r][j], descale, bias));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
-                        const float v = relu2(fmaf(acc[r][j], descale, bias));
-                        pool += (col < width) ? v : 0.f;
-                    }
-            }
-        }
-        pool += __shfl_xor(pool, 32);
-        __syncthreads();
-        if (lane < 32) red[wave * 32 + lane] = pool;
-        __syncthreads();
-        if (tid < 64) {
-            const int t_nt = tid >> 5, t_x = tid & 31;
-            out[int64_t(clip) * 64 + tid] = (red[t_nt * 32 + t_x] + red[(2 + t_nt) * 32 + t_x]) * half_inv_area;
-        }
-    }
-}
-
 // Workgroup = 8 waves with fixed roles, one workgroup per CU (persistent over clips):
 //   waves 0-3  CONSUMERS: (row group, N-tile) MFMA tiles of the current band + bias/ReLU/pool epilogue
 //   waves 4-7  PRODUCERS: conv1 of the NEXT band on the VALU into the other half of a double-buffered LDS tile,
@@ -871,11 +790,10 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
         h_attr_set = true;
     }
     const u32x4* wH = reinterpret_cast<const u32x4*>(packed + L.conv2_h);
-    // WW_CNN_STRUCT: "n16" (default) 12-wave 16x16x32 kernel; "sym" 4-wave symmetric; "spec" 8-wave 32x32x16 roles
+    // WW_CNN_STRUCT (tuning knob): "n16" (default) 12-wave 16x16x32 kernel; "spec" 8-wave 32x32x16 kernel
     static const int h_struct = [] {
         const char* e = getenv("WW_CNN_STRUCT");
-        if (!e) return 2;
-        return e[0] == 'n' ? 2 : (e[0] == 's' && e[1] == 'p') ? 1 : 0;
+        return (e && e[0] == 's') ? 1 : 2;
     }();
     if (n_conv == 2 && split && h_struct == 2) {
         static bool a16 = false;
@@ -887,15 +805,6 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
                            packed + L.conv1_w, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv1_h),
                            reinterpret_cast<const u32x4*>(packed + L.conv2_h16),
                            packed + L.conv2_hs, packed + L.conv2_b, pooled);
-        WW_HIP(hipGetLastError());
-        return WW_OK;
-    }
-    static const int h_sleeps = [] { const char* e = getenv("WW_CNN_STAGGER"); return e ? atoi(e) : 1; }();
-    if (n_conv == 2 && split && h_struct == 0) {
-        const int cus = device_cu_count();
-        hipLaunchKernelGGL(cnn2hs_kernel, dim3(grid), dim3(256), kC2hsLdsBytes, stream, mel, int(n), width,
-                           packed + L.conv1_w, packed + L.conv1_b, wH, packed + L.conv2_hs, packed + L.conv2_b, pooled,
-                           cus, h_sleeps);
         WW_HIP(hipGetLastError());
         return WW_OK;
     }
