@@ -534,13 +534,14 @@ __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh,
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, ph, acc, 0, 0, 0);
         // D: lane&31 = column x, register j <-> channel (j&3) + 8*(j>>2) + 4*h
         const bool col_ok = x < width;
+        const bool full = width == kW;                                 // uniform: skips the per-value column mask
 #pragma unroll
         for (int gch = 0; gch < 4; ++gch) {
             _Float16 hi[4], lo[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t = relu2(acc[4 * gch + e]);                     // 2*relu: the factor is folded into conv2's descale
-                t = col_ok ? t : 0.f;
+                if (!full) t = col_ok ? t : 0.f;
                 hi[e] = static_cast<_Float16>(t);
                 lo[e] = static_cast<_Float16>(t - static_cast<float>(hi[e]));
             }
@@ -640,6 +641,9 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                 return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + 16 * ch + dx) * kPos16 + half * 64));
             };
             half8 ah = frag(0, 0), al = frag(0, 1);
+#ifdef WW_K2_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int it = 0; it < 36; ++it) {
                 half8 ahn = ah, aln = al;
@@ -656,6 +660,9 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                 }
                 ah = ahn; al = aln;
             }
+#ifdef WW_K2_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             // D layout 16x16: lane&15 = channel, register j <-> position 16*ch + 4*(lane>>4) + j
             if (band == 0) pool = 0.f;
             if (width == kW) {

@@ -105,8 +105,11 @@ __device__ __forceinline__ void lds_order() {
 // are branch-free -- clamped address + select -- and all eight stay in flight together.  Otherwise a float4 can
 // straddle clip_len and the tail is fetched element-wise (rare: ragged clip lengths).
 template <bool ALIGNED>
-__device__ __forceinline__ void load_frame(float4 (&sn)[8], const float* __restrict__ clip, int base, int clip_len,
-                                           bool ring, int ring_pos, int ring_len) {
+__device__ __forceinline__ unsigned load_frame(float4 (&sn)[8], const float* __restrict__ clip, int base, int clip_len,
+                                               bool ring, int ring_pos, int ring_len) {
+    // Returns a bit mask of the float4s that lie inside the clip; the caller zeroes the others WHEN IT USES the data,
+    // so that nothing here consumes a loaded value and the eight loads stay asynchronous.
+    unsigned okmask = 0;
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
         const int idx = base + 256 * n1;              // multiple of 4
@@ -114,8 +117,8 @@ __device__ __forceinline__ void load_frame(float4 (&sn)[8], const float* __restr
             const bool ok = idx >= 0 && idx < clip_len;
             int at = ok ? idx : 0;
             if (ring) { at += ring_pos; at = at >= ring_len ? at - ring_len : at; }
-            const float4 v = *reinterpret_cast<const float4*>(clip + at);
-            sn[n1] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            sn[n1] = *reinterpret_cast<const float4*>(clip + at);
+            okmask |= ok ? (1u << n1) : 0u;
         } else {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx >= 0 && idx < clip_len) {
@@ -128,8 +131,10 @@ __device__ __forceinline__ void load_frame(float4 (&sn)[8], const float* __restr
                 }
             }
             sn[n1] = x;
+            okmask |= 1u << n1;
         }
     }
+    return okmask;
 }
 
 #ifdef WW_STAMPS
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     const float2* twp_2 = reinterpret_cast<const float2*>(lds + kOffTwp);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane_id = tid & 63;
+    const int lane = lane_id;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* slab = lds + wave * kSlab;
     float2* slab2 = reinterpret_cast<float2*>(slab);
@@ -189,7 +195,6 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     //   X1: y[k1][n'/2]       at k1*64 + ((n'/2) ^ (8 * ((k1>>1)&1)))
     //   X2: u[reader lane][m] at reader*8 + (m ^ ((reader>>1)&7)),  reader = 8*k1 + k2, m = n''/2
     //   Z : Z[k]              at float2 index k ^ (((k>>4)&3) << 1)
-    const int k1r = lane >> 3, jr = lane & 7;                   // pass-2 role: (k1, j)
 #ifdef WW_STAMPS
     const bool stamp_on = true;
     unsigned long long acc_st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_st = 0;
@@ -202,12 +207,17 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
         float peak = 0.f;
         // the samples of a frame are fetched one frame ahead (8 x dwordx4 per lane in flight under the FFT)
         float4 sn[8];
-        if (aligned) load_frame<true>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len);
-        else load_frame<false>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len);
+        unsigned okmask = aligned ? load_frame<true>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len)
+                                  : load_frame<false>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len);
 
 #pragma unroll 1
         for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
             const int frame = round * kWavesPerBlock + wave;
+            // Opaque copy of the lane id: every swizzled LDS address below is a function of it.  Without this the
+            // compiler hoists ~100 loop-invariant address VGPRs out of the frame loop and spills the prefetched samples.
+            int lane = lane_id;
+            asm volatile("" : "+v"(lane));
+            const int k1r = lane >> 3, jr = lane & 7;                   // pass-2 role: (k1, j)
             const int base_next = (frame + kWavesPerBlock) * kHop - kNfft / 2 + 4 * lane;
 
             STAMP(8);
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             float2 za[8], zb[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
-                const float4 s = sn[n1];
+                const float4 s = (okmask >> n1) & 1u ? sn[n1] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 w = win4[64 * n1 + lane];
                 peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
                 za[n1] = make_float2(s.x * w.x, s.y * w.y);
@@ -284,8 +294,8 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             // next frame's samples: issued here, after the register-hungry FFT passes, and in flight under the
             // power / mel stages (about a third of the frame time, several times the HBM latency)
             if (round + 1 < kFrames / kWavesPerBlock) {
-                if (aligned) load_frame<true>(sn, x, base_next, clip_len, ring, ring_pos, ring_len);
-                else load_frame<false>(sn, x, base_next, clip_len, ring, ring_pos, ring_len);
+                okmask = aligned ? load_frame<true>(sn, x, base_next, clip_len, ring, ring_pos, ring_len)
+                                 : load_frame<false>(sn, x, base_next, clip_len, ring, ring_pos, ring_len);
             }
             // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
             {
