@@ -85,6 +85,35 @@ WW_API int ww_mel_filterbank_host(float* out_host);
 /* periodic Hann window of 2048 points (librosa.stft window='hann') -> [2048] float32. */
 WW_API int ww_hann_window_host(float* out_host);
 
+/* ---- K0: decode + mono + resample + normalise + crop/pad ------------------- */
+/* Replaces the numeric part of AudioProcessor.load_audio = librosa.load(path, sr=16000)
+ * (wakeword_training_script.py:65-71), normalize_audio (:73-76) and pad_or_truncate (:78-83): process_audio_file
+ * :125-133 up to the mel call.  The host reads the file and parses the RIFF header; everything on samples runs here.
+ * The resampler follows scipy.signal.resample_poly's design; librosa's (soxr_hq) differs: unpinned, see DESIGN.md. */
+#define WW_FMT_S16 1
+#define WW_FMT_S24 2
+#define WW_FMT_S32 3
+#define WW_FMT_F32 4
+#define WW_FMT_U8 5
+typedef struct ww_clip_desc {
+    int64_t byte_offset;  /* start of the interleaved sample data of this file inside raw_dev */
+    int64_t n_frames;     /* sample frames in the file */
+    int32_t channels;
+    int32_t sample_rate;
+    int32_t format;       /* WW_FMT_* */
+    int32_t crop_start;   /* first 16 kHz output sample of the 1 s window (host draws it: pad_or_truncate's random crop) */
+    int32_t up, down, half_len, _pad; /* filled by ww_resampler_prepare */
+    const void* taps_dev; /* filled by ww_resampler_prepare (NULL when the file is already 16 kHz) */
+} ww_clip_desc;
+/* The polyphase taps for `sample_rate` -> 16 kHz on the host (no GPU needed); returns the tap count (0 = no filter),
+ * or the count needed when taps_host is NULL. */
+WW_API int ww_resample_taps_host(int32_t sample_rate, float* taps_host, int32_t max_taps, int32_t* up, int32_t* down, int32_t* half_len);
+/* Fill up/down/half_len/taps_dev of one descriptor; uploads the filter for this rate once per device (allocates). */
+WW_API int ww_resampler_prepare(int32_t sample_rate, ww_clip_desc* desc_host);
+/* raw_dev: the files' sample bytes; descs_dev: [n_clips] descriptors in device memory; pcm_out_dev [n_clips][16000]. */
+WW_API int ww_decode_resample(const uint8_t* raw_dev, const ww_clip_desc* descs_dev, int64_t n_clips, int normalize,
+                              float* pcm_out_dev, ww_stream_t stream);
+
 /* ---- K1: log-mel front-end --------------------------------------------------------------- */
 /* Replaces AudioProcessor.normalize_audio (:73-76), the zero-pad branch of pad_or_truncate
  * (:78-83) and AudioProcessor.audio_to_mel (:85-101) =

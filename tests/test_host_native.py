@@ -119,6 +119,20 @@ def test_pack_rejects_bad_state_dicts():
     assert nat.lib.ww_packed_weights_floats(5) == nat.WW_EINVAL
 
 
+def test_resampler_taps_match_scipy_design():
+    from scipy.signal import firwin
+    for sr, (u, d) in {44100: (160, 441), 48000: (1, 3), 8000: (2, 1), 22050: (320, 441), 32000: (1, 2)}.items():
+        up, dn, hl = C.c_int32(), C.c_int32(), C.c_int32()
+        n = nat.lib.ww_resample_taps_host(sr, None, 0, C.byref(up), C.byref(dn), C.byref(hl))
+        assert (up.value, dn.value, hl.value, n) == (u, d, 10 * max(u, d), 20 * max(u, d) + 1)
+        taps = np.zeros(n, np.float32)
+        assert nat.lib.ww_resample_taps_host(sr, taps.ctypes.data, n, None, None, None) == n
+        ref = firwin(n, 1.0 / max(u, d), window=("kaiser", 5.0)) * u     # scipy.signal.resample_poly's filter
+        assert np.abs(taps - ref).max() <= 6e-8 * max(1, u)
+    assert nat.lib.ww_resample_taps_host(16000, None, 0, None, None, None) == 0        # already 16 kHz: no filter
+    assert nat.lib.ww_resample_taps_host(10, None, 0, None, None, None) == nat.WW_EINVAL
+
+
 def test_size_queries_do_not_need_a_gpu():
     assert nat.lib.ww_workspace_bytes(4096, 2) >= 4096 * (2560 + 64) * 4
     assert nat.lib.ww_cnn_scratch_bytes(16, 2) == 0 and nat.lib.ww_cnn_scratch_bytes(16, 3) == 16 * 80 * 64 * 32 * 4

@@ -38,6 +38,17 @@ class StateDict(C.Structure):
     ]
 
 
+class ClipDesc(C.Structure):
+    """struct ww_clip_desc (include/wakeword_amd.h)."""
+    _fields_ = [
+        ("byte_offset", C.c_int64), ("n_frames", C.c_int64), ("channels", C.c_int32), ("sample_rate", C.c_int32),
+        ("format", C.c_int32), ("crop_start", C.c_int32), ("up", C.c_int32), ("down", C.c_int32),
+        ("half_len", C.c_int32), ("_pad", C.c_int32), ("taps_dev", C.c_void_p),
+    ]
+
+
+FMT_S16, FMT_S24, FMT_S32, FMT_F32, FMT_U8 = 1, 2, 3, 4, 5
+
 # name -> (restype, argtypes); kept in one table so tests can check it against the header
 PROTOTYPES = {
     "ww_abi_version": (C.c_int, []),
@@ -48,6 +59,9 @@ PROTOTYPES = {
     "ww_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "ww_mel_filterbank_host": (C.c_int, [C.c_void_p]),
     "ww_hann_window_host": (C.c_int, [C.c_void_p]),
+    "ww_resample_taps_host": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ww_resampler_prepare": (C.c_int, [C.c_int32, C.POINTER(ClipDesc)]),
+    "ww_decode_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "ww_logmel_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "ww_packed_weights_floats": (C.c_int64, [C.c_int32]),
     "ww_pack_weights_host": (C.c_int, [C.POINTER(StateDict), C.c_void_p]),

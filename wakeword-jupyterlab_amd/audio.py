@@ -26,6 +26,28 @@ from . import ops
 from .config import AudioConfig, check_audio_config
 
 
+def _parse_wav(data: bytes):
+    """RIFF/WAVE header walk -> (format tag, channels, sample rate, bits, data offset, data length)."""
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError("not a RIFF/WAVE file")
+    pos, fmt, where = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], int.from_bytes(data[pos + 4:pos + 8], "little")
+        if cid == b"fmt ":
+            body = data[pos + 8:pos + 8 + size]
+            tag, ch, sr = int.from_bytes(body[0:2], "little"), int.from_bytes(body[2:4], "little"), int.from_bytes(body[4:8], "little")
+            bits = int.from_bytes(body[14:16], "little")
+            if tag == 0xFFFE and len(body) >= 26:
+                tag = int.from_bytes(body[24:26], "little")
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            where = (pos + 8, min(size, len(data) - pos - 8))
+        pos += 8 + size + (size & 1)
+    if fmt is None or where is None:
+        raise ValueError("missing fmt/data chunk")
+    return fmt + where
+
+
 def _read_wav(path: str):
     """Minimal RIFF/WAVE reader: 8/16/24/32-bit PCM and 32-bit float, any channel count -> (float32 [n, ch], sr)."""
     with open(path, "rb") as f:
@@ -138,6 +160,52 @@ class AudioProcessor:
         if t.device.type != "cuda":
             t = t.to(self._dev(), non_blocking=True)
         return ops.logmel(t, normalize)
+
+    def load_clips_gpu(self, paths, normalize: bool = True):
+        """Host: read the files and parse their RIFF headers.  GPU (kernel K0): sample conversion, mono mix, polyphase
+        resample to 16 kHz, whole-file peak normalisation, random crop / zero pad to 1 s -- process_audio_file :125-133
+        up to the mel call.  Returns (device tensor [B, 16000], ok mask); unreadable files give a zero row, ok False."""
+        import ctypes as C
+        from . import _native as nat
+        dev = self._dev()
+        n = int(self.config.SAMPLE_RATE * self.config.DURATION)
+        fmt_of = {(1, 16): nat.FMT_S16, (1, 24): nat.FMT_S24, (1, 32): nat.FMT_S32, (3, 32): nat.FMT_F32, (1, 8): nat.FMT_U8}
+        descs = (nat.ClipDesc * len(paths))()
+        chunks, ok, offset, prepared = [], np.zeros(len(paths), dtype=bool), 0, {}
+        for i, path in enumerate(paths):
+            try:
+                with open(path, "rb") as f:
+                    data = f.read()
+                tag, ch, sr, bits, start, length = _parse_wav(data)
+                if (tag, bits) not in fmt_of or ch < 1:
+                    raise ValueError(f"unsupported WAV encoding tag={tag} bits={bits}")
+                frame_bytes = ch * bits // 8
+                frames = length // frame_bytes
+                if sr not in prepared:
+                    proto = nat.ClipDesc()
+                    with torch.cuda.device(dev):
+                        nat.check(nat.lib.ww_resampler_prepare(sr, C.byref(proto)))
+                    prepared[sr] = proto
+                d, proto = descs[i], prepared[sr]
+                d.byte_offset, d.n_frames, d.channels, d.sample_rate, d.format = offset, frames, ch, sr, fmt_of[(tag, bits)]
+                d.up, d.down, d.half_len, d.taps_dev = proto.up, proto.down, proto.half_len, proto.taps_dev
+                n_out = -(-frames * proto.up // proto.down)
+                d.crop_start = random.randint(0, n_out - n) if n_out > n else 0      # pad_or_truncate's random crop (:79-81)
+                body = data[start:start + frames * frame_bytes]
+                body += b"\0" * (-len(body) % 16)                                    # keep every file 16-byte aligned
+                chunks.append(body)
+                offset += len(body)
+                ok[i] = True
+            except Exception as e:                                                   # reference: print and carry on (:66-71)
+                print(f"Error loading {path}: {e}")
+                descs[i].n_frames, descs[i].channels, descs[i].format, descs[i].up, descs[i].down = 0, 1, nat.FMT_S16, 1, 1
+        raw = torch.frombuffer(bytearray(b"".join(chunks) or b"\0" * 16), dtype=torch.uint8).to(dev)
+        desc_t = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev) if len(paths) else torch.zeros(1, dtype=torch.uint8, device=dev)
+        out = torch.empty((len(paths), n), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            nat.check(nat.lib.ww_decode_resample(C.c_void_p(raw.data_ptr()), C.c_void_p(desc_t.data_ptr()), len(paths), int(bool(normalize)),
+                                                 C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out, ok
 
     def load_clips(self, paths, target_length=None):
         """Decode, peak-normalise and crop/pad a list of files on the host, in the reference's order

@@ -43,14 +43,19 @@ class WakewordDataset(Dataset):
             mel_spec = np.zeros((self.processor.config.N_MELS, N_FRAMES))
         return torch.FloatTensor(np.asarray(mel_spec, dtype=np.float32)).unsqueeze(0), torch.LongTensor([self.labels[idx]])
 
-    def batches(self, batch_size=16):
-        """Yield (data [B,1,80,32] on the GPU, target [B,1] on the GPU) in file order."""
+    def batches(self, batch_size=16, gpu_decode=True):
+        """Yield (data [B,1,80,32] on the GPU, target [B,1] on the GPU) in file order.
+        gpu_decode=True: the host only reads bytes; decode/resample/normalise/crop run in kernel K0, log-mel in K1."""
         dev = self.processor._dev()
         for s in range(0, len(self.files), batch_size):
             paths = self.files[s:s + batch_size]
-            pcm, ok = self.processor.load_clips(paths)
-            # load_clips already peak-normalised each file before the crop/pad, as the reference does (:131-133)
-            data = self.processor.mel_batch(torch.from_numpy(pcm).to(dev), normalize=False)
+            if gpu_decode:
+                pcm_dev, ok = self.processor.load_clips_gpu(paths, normalize=True)
+            else:
+                pcm, ok = self.processor.load_clips(paths)
+                pcm_dev = torch.from_numpy(pcm).to(dev)
+            # both loaders already peak-normalised each file before the crop/pad, as the reference does (:131-133)
+            data = self.processor.mel_batch(pcm_dev, normalize=False)
             if not ok.all():
                 data[torch.from_numpy(~ok).to(dev)] = 0.0
             target = torch.tensor(self.labels[s:s + batch_size], dtype=torch.long, device=dev).unsqueeze(1)
