@@ -96,7 +96,8 @@ def test_packed_weight_image_layout(arch):
     lane, j = np.meshgrid(np.arange(64), np.arange(8), indexing="ij")
     k = 8 * (lane >> 5) + j
     w1b = np.concatenate([sd["conv1.weight"].reshape(32, 9), sd["conv1.bias"][:, None], np.zeros((32, 6), np.float32)], 1).astype(np.float64)
-    assert np.abs((c1[0] + c1[1]) - w1b[lane & 31, k]).max() <= 2.0 ** -22
+    mrow = lane & 31
+    assert np.abs((c1[0] + c1[1]) - w1b[(mrow & 3) + 4 * (mrow >> 3) + 16 * ((mrow >> 2) & 1), k]).max() <= 2.0 ** -22
     h16 = take(4 * 9 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(4, 9, 2, 64, 8)       # [nt16][ks = dx*3+dy][hi/lo][lane][j]
     nt, dx, dy, lane, j = np.meshgrid(np.arange(4), np.arange(3), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
     want16 = w2[16 * nt + (lane & 15), 8 * (lane >> 4) + j, dy, dx] * 2.0 ** S

@@ -488,68 +488,124 @@ __device__ __forceinline__ void conv1_band_split16(const float* __restrict__ mel
 // with the column on the lane and 16 channels in registers: 2*relu, split, 8-byte stores into the position records.
 constexpr int kMelHRS = 36;                              // f16 plane row stride (columns -1..34)
 constexpr int kMelHPlane = (kH + 2) * kMelHRS;           // halfs per plane
+// One row of conv1 on the matrix cores, split into its three stages so that a producer can run the stages of its
+// (up to three) rows side by side: the LDS, MFMA and VALU latencies of one row hide under the other rows' work.
+struct Conv1Row {
+    half8 ph, pl;       // patch operand B[k = 8h + j][x], hi and lo halves
+    f32x16 acc;
+    bool ok;            // row inside the image (uniform)
+};
+
+__device__ __forceinline__ void conv1_row_gather(Conv1Row& r, const _Float16* __restrict__ mh, const _Float16* __restrict__ ml,
+                                                 int y, int x, int h) {
+    r.ok = y >= 0 && y < kH;
+    const int yy = r.ok ? y : 0;
+    const _Float16 one = static_cast<_Float16>(1.0f), zero = static_cast<_Float16>(0.0f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                      // lower half-wave: taps 0..7; upper: tap 8, the bias tap (1.0), zeros
+        const int o0 = (yy + j / 3) * kMelHRS + x + j % 3;             // tile coords: row y+dy-1 -> y+dy, col x+dx-1 -> x+dx
+        const _Float16 vh0 = mh[o0], vl0 = ml[o0];
+        if (j == 0) {
+            const int o1 = (yy + 2) * kMelHRS + x + 2;                 // tap 8 (dy = 2, dx = 2)
+            const _Float16 vh1 = mh[o1], vl1 = ml[o1];
+            r.ph[j] = h ? vh1 : vh0;
+            r.pl[j] = h ? vl1 : vl0;
+        } else if (j == 1) {
+            r.ph[j] = h ? one : vh0;
+            r.pl[j] = h ? zero : vl0;
+        } else {
+            r.ph[j] = h ? zero : vh0;
+            r.pl[j] = h ? zero : vl0;
+        }
+    }
+}
+
+__device__ __forceinline__ void conv1_row_mfma(Conv1Row& r, half8 a1h, half8 a1l) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r.acc[j] = 0.f;
+    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, r.ph, r.acc, 0, 0, 0);
+    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, r.pl, r.acc, 0, 0, 0);
+    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, r.ph, r.acc, 0, 0, 0);
+}
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// x ~= hi + lo for two values at once: v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32
+// (2.5 VALU instructions per value instead of 6 for the scalar form; same round-to-nearest result)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const float2_t v = {a, b};
+    const half2_t h = __builtin_convertvector(v, half2_t);
+    const half2_t l = __builtin_convertvector(v - __builtin_convertvector(h, float2_t), half2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// D: lane&31 = column x; the weight rows are permuted on the host so that register j holds channel 16*h + j:
+// 2*relu, hi/lo split, and the lane's 16 contiguous channels go out as two 16-byte stores per half.
+__device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restrict__ rec, bool keep, bool full) {
+#pragma unroll
+    for (int g8 = 0; g8 < 2; ++g8) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            t[e] = relu2(r.acc[8 * g8 + e]);                           // 2*relu: the factor is folded into conv2's descale
+            if (!full) t[e] = keep ? t[e] : 0.f;
+        }
+        u32x4 vh, vl;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t hh, ll;
+            split2(t[2 * d], t[2 * d + 1], hh, ll);
+            vh[d] = hh;
+            vl[d] = ll;
+        }
+        *reinterpret_cast<u32x4*>(rec + g8 * 16) = vh;
+        *reinterpret_cast<u32x4*>(rec + 64 + g8 * 16) = vl;
+    }
+}
+
+// conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
+//   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
+// The log-mel tile is kept as two f16 planes (hi, lo) so the patch operand needs no conversions.
+// Producer pw handles tile rows q = pw, pw + 4, pw + 8 (< 10) of the band, all three in flight together.
 __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const _Float16* __restrict__ ml,
                                                 char* __restrict__ act, half8 a1h, half8 a1l, int y0, int width,
                                                 int pw, int lane) {
     const int x = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int q = pw; q < kARows; q += 4) {
-        const int y = y0 - 1 + q;
-        char* rec = act + (q * kRS + x + 1) * kPos16 + h * 8;        // channels 4h.. of each group of 8
-        if (y < 0 || y >= kH) {                                        // outside the image: conv2's zero padding
+    const bool full = width == kW;                       // uniform: skips the per-value column mask
+    const bool third = pw + 8 < kARows;                  // uniform: producers 0 and 1 own three rows
+    Conv1Row r0, r1, r2;
+    conv1_row_gather(r0, mh, ml, y0 - 1 + pw, x, h);
+    conv1_row_gather(r1, mh, ml, y0 - 1 + pw + 4, x, h);
+    if (third) conv1_row_gather(r2, mh, ml, y0 - 1 + pw + 8, x, h);
+#ifdef WW_ABL_P_NOMFMA
 #pragma unroll
-            for (int gch = 0; gch < 4; ++gch) {
-                *reinterpret_cast<uint2*>(rec + gch * 16) = make_uint2(0u, 0u);
-                *reinterpret_cast<uint2*>(rec + 64 + gch * 16) = make_uint2(0u, 0u);
-            }
-            continue;
-        }
-        // patch operand B[k = 8h + j][x]: taps 0..7 on the lower half-wave; tap 8, the bias tap (1.0) and zeros on the upper
-        half8 ph, pl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = j;                                           // tap index for h == 0
-            const int dy = k / 3, dx = k % 3;
-            const int o0 = (y + dy) * kMelHRS + x + dx;                // tile coords: row y+dy-1 -> y+dy, col x+dx-1 -> x+dx
-            const int o1 = (y + 2) * kMelHRS + x + 2;                  // tap 8 (dy = 2, dx = 2)
-            const _Float16 one = static_cast<_Float16>(1.0f), zero = static_cast<_Float16>(0.0f);
-            const _Float16 vh0 = mh[o0], vl0 = ml[o0];
-            if (j == 0) {
-                const _Float16 vh1 = mh[o1], vl1 = ml[o1];
-                ph[j] = h ? vh1 : vh0;
-                pl[j] = h ? vl1 : vl0;
-            } else if (j == 1) {
-                ph[j] = h ? one : vh0;
-                pl[j] = h ? zero : vl0;
-            } else {
-                ph[j] = h ? zero : vh0;
-                pl[j] = h ? zero : vl0;
-            }
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, ph, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, pl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, ph, acc, 0, 0, 0);
-        // D: lane&31 = column x, register j <-> channel (j&3) + 8*(j>>2) + 4*h
-        const bool col_ok = x < width;
-        const bool full = width == kW;                                 // uniform: skips the per-value column mask
-#pragma unroll
-        for (int gch = 0; gch < 4; ++gch) {
-            _Float16 hi[4], lo[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = relu2(acc[4 * gch + e]);                     // 2*relu: the factor is folded into conv2's descale
-                if (!full) t = col_ok ? t : 0.f;
-                hi[e] = static_cast<_Float16>(t);
-                lo[e] = static_cast<_Float16>(t - static_cast<float>(hi[e]));
-            }
-            *reinterpret_cast<uint2*>(rec + gch * 16) = make_uint2(pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]));
-            *reinterpret_cast<uint2*>(rec + 64 + gch * 16) = make_uint2(pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]));
-        }
-    }
+    for (int j = 0; j < 16; ++j) { r0.acc[j] = float(r0.ph[j & 7]); r1.acc[j] = float(r1.pl[j & 7]); r2.acc[j] = float(r2.ph[j & 7]); }
+#else
+    conv1_row_mfma(r0, a1h, a1l);
+    conv1_row_mfma(r1, a1h, a1l);
+    if (third) conv1_row_mfma(r2, a1h, a1l);
+#endif
+    char* rec = act + (pw * kRS + x + 1) * kPos16 + h * 32;            // this lane's 16 channels 16h..16h+15
+    const bool col_ok = x < width;
+    // rows outside the image are conv2's zero padding: `keep` false zeroes them (never `full` for such a row)
+#ifdef WW_ABL_P_NOSTORE
+    if (r0.acc[0] + r1.acc[1] + (third ? r2.acc[2] : 0.f) == 12345.678f) *reinterpret_cast<float*>(rec) = 1.f;
+#else
+    conv1_row_store(r0, rec, col_ok && r0.ok, full && r0.ok);
+    conv1_row_store(r1, rec + 4 * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
+    if (third) conv1_row_store(r2, rec + 8 * kRS * kPos16, col_ok && r2.ok, full && r2.ok);
+#endif
 }
+
+#ifdef WW_STAMPS
+__device__ unsigned long long g_cnn_stamps[16];
+#define CSTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+    cst[i] += t__ - clast; clast = t__; } while (0)
+#else
+#define CSTAMP(i) do {} while (0)
+#endif
 
 __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict__ mel, int n, int width,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
@@ -583,6 +639,12 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     if (!consumer) {
         a1h = __builtin_bit_cast(half8, w1H[lane]);
         a1l = __builtin_bit_cast(half8, w1H[64 + lane]);
+#ifndef WW_K2_NO_PRODPRIO
+        // The producers are VALU streams sharing each SIMD's issue port with two MFMA streams (an MFMA holds the port
+        // for 8 of its 16 cycles); issue is arbitrated by priority, then age.  Without this the producers starve and
+        // the consumers wait a third of the time at the band barrier.
+        __builtin_amdgcn_s_setprio(3);
+#endif
     }
     for (int i = tid; i < kC2h16Lds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
     __syncthreads();
@@ -623,8 +685,13 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     __syncthreads();
 
     float pool = 0.f;
+#ifdef WW_STAMPS
+    unsigned long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clast = 0;
+    CSTAMP(7);
+#endif
     for (int g = 0; g < steps; ++g) {
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
+        CSTAMP(0);
         if (consumer) {
             if (band == 0 && g > 0 && wave == 0) write_pooled(k - 1);
             const char* ap = act0 + (g & 1) * kH16Act + ((rg * 4) * kRS + pi) * kPos16 + kq * 16;
@@ -663,6 +730,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
 #ifdef WW_K2_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
+            CSTAMP(1);
             // D layout 16x16: lane&15 = channel, register j <-> position 16*ch + 4*(lane>>4) + j
             if (band == 0) pool = 0.f;
             if (width == kW) {
@@ -688,15 +756,32 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                 p2 += __shfl_xor(p2, 32);
                 if (lane < 16) red[wave * 16 + lane] = p2;
             }
+            CSTAMP(2);
         } else if (g + 1 < steps) {
+#ifndef WW_ABL_P_NONE
             produce(g + 1);
+#endif
             const int k1 = (g + 1) / (kH / kBand);
             if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);
+            CSTAMP(3);
         }
         __syncthreads();
+        CSTAMP(4);
     }
     if (consumer && wave == 0 && steps > 0) write_pooled(my_clips - 1);
+#ifdef WW_STAMPS
+    if (lane == 0 && blockIdx.x == 7 && (wave == 1 || wave == 9))
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_cnn_stamps[i + (wave == 9 ? 8 : 0)], cst[i]);
+#endif
 }
+#ifdef WW_STAMPS
+extern "C" __attribute__((visibility("default"))) int ww_debug_cnn_stamps(unsigned long long* out) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cnn_stamps), sizeof(z)) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cnn_stamps), z, sizeof(z));
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // conv3 (64->128) + ReLU + pool for the 3-conv WakewordModel.  512 threads: wave = (K-half kh, N-tile nt);

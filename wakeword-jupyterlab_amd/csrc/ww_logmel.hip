@@ -30,15 +30,27 @@ constexpr int kPartialInSlab = 1032;
 static_assert(kPartialInSlab + kPieces <= kSlab, "piece sums must fit behind the power spectrum");
 constexpr int kOffMel = kWavesPerBlock * kSlab;
 constexpr int kOffRed = kOffMel + kMels * kMelStride;
-constexpr int kOffPw = kOffRed + 16;                    // [2][kPieces][4]
+constexpr int kOffPw = kOffRed + 16;                    // [2][kPieces][4] (lean variant: unused, kept for the offsets)
+#ifndef WW_K1_FAT_LDS
+constexpr int kOffPinfo = kOffPw;                       // piece weights stay in global memory
+#else
 constexpr int kOffPinfo = kOffPw + 2 * kPieces * 4;     // [kPieces] ints
+#endif
 constexpr int kOffFp0 = kOffPinfo + kPieces;            // [80] ints
 constexpr int kOffFcnt = kOffFp0 + kMels;               // [80] ints
 constexpr int kOffTw2 = kOffFcnt + kMels;               // [7][16] float2
 constexpr int kOffTwp = kOffTw2 + 7 * 16 * 2;           // [512] float2
 constexpr int kOffTw1 = kOffTwp + 512 * 2;              // [7][128] float2
 constexpr int kOffWin = kOffTw1 + 7 * 128 * 2;          // [2048]
+#ifndef WW_K1_FAT_LDS
+// lean variant: window, pass-1 twiddles and piece weights are read through L1 from the global table instead
+// (25 KB less LDS per workgroup: 3 workgroups per CU instead of 2)
+constexpr int kLdsFloats = kOffTw1;
+constexpr int kBlocksPerCu = 3;
+#else
 constexpr int kLdsFloats = kOffWin + kNfft;
+constexpr int kBlocksPerCu = 2;
+#endif
 static_assert(kOffPw % 4 == 0 && kOffTw2 % 4 == 0 && kOffTwp % 2 == 0 && kOffTw1 % 4 == 0 && kOffWin % 4 == 0, "LDS table alignment");
 
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -145,7 +157,8 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
+template <bool ALIGNED>
+__global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
                                                              int clip_len, int n_clips, int normalize,
                                                              const int32_t* __restrict__ ring_pos_p, int ring_len,
                                                              const LogmelTables* __restrict__ tb,
@@ -153,7 +166,11 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mel = lds + kOffMel;                                 // [80][33]
     float* red = lds + kOffRed;                                 // [16]
+#ifndef WW_K1_FAT_LDS
+    const float4* pw4 = reinterpret_cast<const float4*>(&tb->piece_w[0][0][0]);
+#else
     const float4* pw4 = reinterpret_cast<const float4*>(lds + kOffPw);   // [2][kPieces]
+#endif
     const int* pinfo = reinterpret_cast<const int*>(lds + kOffPinfo);
     const int* fp0 = reinterpret_cast<const int*>(lds + kOffFp0);
     const int* fcnt = reinterpret_cast<const int*>(lds + kOffFcnt);
@@ -168,11 +185,18 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     float2* slab2 = reinterpret_cast<float2*>(slab);
     float4* slab4 = reinterpret_cast<float4*>(slab);
     float* partial = slab + kPartialInSlab;                     // this wave's piece sums, filter-major
+#ifndef WW_K1_FAT_LDS
+    const float4* tw1_4 = reinterpret_cast<const float4*>(&tb->tw1[0][0]);
+    const float4* win4 = reinterpret_cast<const float4*>(&tb->window[0]);
+#else
     const float4* tw1_4 = reinterpret_cast<const float4*>(lds + kOffTw1);   // [7][64] float4 = twiddles of n' = 2l, 2l+1
     const float4* win4 = reinterpret_cast<const float4*>(lds + kOffWin);
+#endif
 
     // ---- all tables into LDS once per workgroup (conflict-free, lane-contiguous reads) ----
+#ifdef WW_K1_FAT_LDS
     for (int i = tid; i < 2 * kPieces * 4; i += kThreads) lds[kOffPw + i] = (&tb->piece_w[0][0][0])[i];
+#endif
     for (int i = tid; i < kPieces; i += kThreads) reinterpret_cast<int*>(lds)[kOffPinfo + i] = tb->piece_info[i];
     if (tid < kMels) {
         reinterpret_cast<int*>(lds)[kOffFp0 + tid] = tb->filt_p0[tid];
@@ -180,11 +204,12 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     }
     for (int i = tid; i < 7 * 16 * 2; i += kThreads) lds[kOffTw2 + i] = (&tb->tw2[0][0].x)[i];
     for (int i = tid; i < 512 * 2; i += kThreads) lds[kOffTwp + i] = (&tb->twp[0].x)[i];
+#ifdef WW_K1_FAT_LDS
     for (int i = tid; i < 7 * 128 * 2; i += kThreads) lds[kOffTw1 + i] = (&tb->tw1[0][0].x)[i];
     for (int i = tid; i < kNfft; i += kThreads) lds[kOffWin + i] = tb->window[i];
+#endif
     const int ring_pos = ring_pos_p ? *ring_pos_p : 0;
     const bool ring = ring_pos_p != nullptr;
-    const bool aligned = (clip_len & 3) == 0;        // uniform: picks the branch-free frame loads
     __syncthreads();
     // this lane's filters in the per-frame combine: f = lane and f = lane + 64 (< 80)
     const int my_p0a = fp0[lane], my_cnta = fcnt[lane];
@@ -201,14 +226,20 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
     STAMP(9);
 #endif
 
+    // the samples of a frame are fetched one frame ahead (8 x dwordx4 per lane in flight under the FFT); the chain runs
+    // across clip boundaries, so only the very first frame of a workgroup is loaded synchronously
+    float4 sn[8];
+    unsigned okmask = 0;
+    if (int(blockIdx.x) < n_clips)
+        okmask = load_frame<ALIGNED>(sn, pcm + int64_t(blockIdx.x) * clip_stride, wave * kHop - kNfft / 2 + 4 * lane, clip_len,
+                                     ring, ring_pos, ring_len);
 #pragma unroll 1
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
         const float* __restrict__ x = pcm + int64_t(clip) * clip_stride;
+        const bool has_next_clip = clip + int(gridDim.x) < n_clips;
+        const float* __restrict__ x_next = has_next_clip ? x + int64_t(gridDim.x) * clip_stride : x;
         float peak = 0.f;
-        // the samples of a frame are fetched one frame ahead (8 x dwordx4 per lane in flight under the FFT)
-        float4 sn[8];
-        unsigned okmask = aligned ? load_frame<true>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len)
-                                  : load_frame<false>(sn, x, wave * kHop - kNfft / 2 + 4 * lane, clip_len, ring, ring_pos, ring_len);
+        // (sn, okmask) were prefetched: by the prologue for the first clip, by the previous clip's last frame otherwise
 
 #pragma unroll 1
         for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
@@ -293,9 +324,12 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const float* __rest
             STAMP(2);
             // next frame's samples: issued here, after the register-hungry FFT passes, and in flight under the
             // power / mel stages (about a third of the frame time, several times the HBM latency)
-            if (round + 1 < kFrames / kWavesPerBlock) {
-                okmask = aligned ? load_frame<true>(sn, x, base_next, clip_len, ring, ring_pos, ring_len)
-                                 : load_frame<false>(sn, x, base_next, clip_len, ring, ring_pos, ring_len);
+            {
+                const bool last = round + 1 == kFrames / kWavesPerBlock;            // uniform: data select, no branch
+                const float* __restrict__ xs = last ? x_next : x;
+                const int bs = last ? wave * kHop - kNfft / 2 + 4 * lane : base_next;
+                const unsigned m = load_frame<ALIGNED>(sn, xs, bs, clip_len, ring, ring_pos, ring_len);
+                okmask = (last && !has_next_clip) ? 0u : m;
             }
             // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
             {
@@ -418,16 +452,21 @@ int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_
     if (n_clips == 0) return WW_OK;
     const LogmelTables* tb = device_tables();
     if (!tb) return WW_EHIP;
-    const int64_t resident = int64_t(device_cu_count()) * 2;      // LDS and VGPRs admit 2 workgroups per CU
+    const int64_t resident = int64_t(device_cu_count()) * kBlocksPerCu;   // what LDS and VGPRs admit per CU
     const int grid = int(n_clips < resident ? n_clips : resident);
     const size_t lds_bytes = sizeof(float) * kLdsFloats;
     static bool lds_attr_set = false;   // just over 64 KiB of dynamic LDS: needs the opt-in once per process
     if (!lds_attr_set) {
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
         lds_attr_set = true;
     }
-    hipLaunchKernelGGL(logmel_kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
-                       int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
+    if ((clip_len & 3) == 0)   // 16000-sample clips and the streaming ring: branch-free frame loads
+        hipLaunchKernelGGL(logmel_kernel<true>, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
+                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
+    else
+        hipLaunchKernelGGL(logmel_kernel<false>, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
+                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }

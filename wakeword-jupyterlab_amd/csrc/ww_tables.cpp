@@ -214,12 +214,15 @@ static float pack_conv2_f16x3(const float* w, float* out_words, float* out_words
 }
 
 // conv1 weight [32][1][3][3] + bias as the A operand of v_mfma_f32_32x32x16_f16 (M = channel, K = 9 taps + bias tap):
-// lane (m = lane&31, h = lane>>5) holds A[m][k = 8h + j]: k < 9 -> w1[m][k], k == 9 -> b1[m] (its patch value is 1.0), else 0.
+// lane (m = lane&31, h = lane>>5) holds A[m][k = 8h + j]: k < 9 -> w1[c][k], k == 9 -> b1[c] (its patch value is 1.0), else 0,
+// where c = (m&3) + 4*(m>>3) + 16*((m>>2)&1): the MFMA's D rows are permuted so that an output lane (which holds rows
+// (j&3) + 8*(j>>2) + 4*(lane>>5), j = 0..15) ends up with the 16 CONTIGUOUS channels 16*(lane>>5) + j.
 static void pack_conv1_f16x3(const float* w, const float* b, float* out_words) {
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
     for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
-            const int m = lane & 31, k = 8 * (lane >> 5) + j;
+            const int mrow = lane & 31, k = 8 * (lane >> 5) + j;
+            const int m = (mrow & 3) + 4 * (mrow >> 3) + 16 * ((mrow >> 2) & 1);
             const float v = k < 9 ? w[m * 9 + k] : (k == 9 ? b[m] : 0.0f);
             const _Float16 hi = static_cast<_Float16>(v);
             const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
