@@ -223,6 +223,23 @@ def test_full_batch_properties_4096(ops, dev):
     assert np.abs(yr[0, :8].cpu().numpy() - ref).max() <= LOGIT_TOL
 
 
+@pytest.mark.parametrize("arch", ["simple", "full"])
+@pytest.mark.parametrize("n", [255, 257, 517, 1030])
+def test_ragged_batch_sizes_agree_with_small_batches(ops, dev, arch, n):
+    # persistent kernels loop over clips with grid = resident workgroups: batch sizes around the CU count (256) and
+    # not divisible by anything must give, clip for clip, exactly what small batches give
+    base = pkg.synth.make_clips(200, 32)
+    pcm = torch.from_numpy(np.tile(base, (n // 32 + 1, 1))[:n] * np.linspace(1.0, 0.5, n, dtype=np.float32)[:, None]).to(dev)
+    m = _model(arch, pkg.synth.make_state_dict(arch, seed=5), dev)
+    with torch.no_grad():
+        whole = m.forward_pcm(pcm)
+        parts = torch.cat([m.forward_pcm(pcm[s:s + 37]) for s in range(0, n, 37)])
+        mel_whole = ops.logmel(pcm, True)
+        mel_parts = torch.cat([ops.logmel(pcm[s:s + 37], True) for s in range(0, n, 37)])
+    assert torch.equal(mel_whole, mel_parts)
+    assert torch.equal(whole, parts)
+
+
 def test_custom_ops_are_registered(ops, dev):
     for name in ("logmel", "cnn_pool", "lstm_fc", "cnn_lstm_forward", "forward_pcm"):
         assert hasattr(torch.ops.wakeword_amd, name)

@@ -92,6 +92,13 @@ def test_packed_weight_image_layout(arch):
     want = w2[32 * nt + (lane & 31), 16 * cb + 8 * (lane >> 5) + j, dy, dx] * 2.0 ** S
     got = (h32[:, :, 0] + h32[:, :, 1]).reshape(2, 2, 3, 3, 64, 8)                                   # ks = (cb*3 + dx)*3 + dy
     assert np.abs(got - want).max() <= np.abs(want).max() * 2.0 ** -21
+    if n_conv == 3:
+        w3 = sd["conv3.weight"].astype(np.float64)
+        h3 = take(8 * 18 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(8, 18, 2, 64, 8)   # [nt16][ks][hi/lo][lane][j]
+        S3 = -int(round(np.log2(float(take(4)[0]))))
+        nt3, cb3, dx3, dy3, lane3, j3 = np.meshgrid(np.arange(8), np.arange(2), np.arange(3), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
+        want3 = w3[16 * nt3 + (lane3 & 15), 32 * cb3 + 8 * (lane3 >> 4) + j3, dy3, dx3] * 2.0 ** S3     # ks = (cb*3 + dx)*3 + dy
+        assert np.abs((h3[:, :, 0] + h3[:, :, 1]).reshape(8, 2, 3, 3, 64, 8) - want3).max() <= np.abs(want3).max() * 2.0 ** -21
     c1 = take(2 * 64 * 4).view(np.float16).astype(np.float64).reshape(2, 64, 8)                      # conv1 A operand: taps + bias tap
     lane, j = np.meshgrid(np.arange(64), np.arange(8), indexing="ij")
     k = 8 * (lane >> 5) + j

@@ -607,6 +607,9 @@ __device__ unsigned long long g_cnn_stamps[16];
 #define CSTAMP(i) do {} while (0)
 #endif
 
+// POOL: out = pooled [n][64].   !POOL (3-conv model): out = relu(conv2) already split for conv3, as f16
+// [n][80 rows][32 columns][64 ci hi | 64 ci lo] (256 bytes per position, zero beyond `width`).
+template <bool POOL>
 __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict__ mel, int n, int width,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const u32x4* __restrict__ w1H,
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
         CSTAMP(0);
         if (consumer) {
-            if (band == 0 && g > 0 && wave == 0) write_pooled(k - 1);
+            if (POOL && band == 0 && g > 0 && wave == 0) write_pooled(k - 1);
             const char* ap = act0 + (g & 1) * kH16Act + ((rg * 4) * kRS + pi) * kPos16 + kq * 16;
             f32x4 acc[4][2];
 #pragma unroll
@@ -732,8 +735,27 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
 #endif
             CSTAMP(1);
             // D layout 16x16: lane&15 = channel, register j <-> position 16*ch + 4*(lane>>4) + j
+            if constexpr (!POOL) {
+                _Float16* o16 = reinterpret_cast<_Float16*>(out);
+                const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int xx = 16 * c + 4 * kq + j, y = band * kBand + rg * 4 + r;
+                            float v = 0.5f * relu2(fmaf(acc[r][c][j], descale, bias));
+                            v = xx < width ? v : 0.f;
+                            const _Float16 hi = static_cast<_Float16>(v);
+                            const int64_t rec = ((clip * kH + y) * kW + xx) * 128 + 16 * nt + pi;
+                            o16[rec] = hi;
+                            o16[rec + 64] = static_cast<_Float16>(v - static_cast<float>(hi));
+                        }
+            }
             if (band == 0) pool = 0.f;
-            if (width == kW) {
+            if constexpr (!POOL) {
+            } else if (width == kW) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -751,7 +773,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                             pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
                         }
             }
-            if (band == kH / kBand - 1) {
+            if (POOL && band == kH / kBand - 1) {
                 float p2 = pool + __shfl_xor(pool, 16);
                 p2 += __shfl_xor(p2, 32);
                 if (lane < 16) red[wave * 16 + lane] = p2;
@@ -768,7 +790,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         __syncthreads();
         CSTAMP(4);
     }
-    if (consumer && wave == 0 && steps > 0) write_pooled(my_clips - 1);
+    if (POOL && consumer && wave == 0 && steps > 0) write_pooled(my_clips - 1);
 #ifdef WW_STAMPS
     if (lane == 0 && blockIdx.x == 7 && (wave == 1 || wave == 9))
         for (int i = 0; i < 8; ++i) atomicAdd(&g_cnn_stamps[i + (wave == 9 ? 8 : 0)], cst[i]);
@@ -862,6 +884,118 @@ __global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3 (64 -> 128) + ReLU + pool, split precision (3-conv WakewordModel).  Input = relu(conv2) as written by
+// cnn2h16_kernel<false>: f16 records [row][column][64 ci hi | 64 ci lo].  8 waves = 8 N-tiles of 16 channels; a wave's
+// 144 B-operand VGPRs (18 k-steps x hi/lo) stay resident; band = 4 output rows; the 6-row tile (records padded to 288
+// bytes: conflict-free 16x16x32 fragment reads) is double-buffered and the next band's tile is fetched into registers
+// at the top of a step and written to LDS behind the MFMAs (issue early / write late).
+// ------------------------------------------------------------------------------------------------
+constexpr int kRec3 = 288;
+constexpr int kT3Rows = 6;
+constexpr int kT3Bytes = kT3Rows * kRS * kRec3;              // 58,752
+constexpr int kC3hLds = 2 * kT3Bytes;
+
+__global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restrict__ in, int n, int width,
+                                                       const u32x4* __restrict__ wH, const float* __restrict__ hs,
+                                                       const float* __restrict__ b3, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nt = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pi = lane & 15, kq = lane >> 4;
+
+    half8 bh[18], bl[18];
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+        bh[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 0) * 64 + lane]);
+        bl[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 1) * 64 + lane]);
+    }
+    const float bias = b3[16 * nt + pi];
+    const float descale = hs[0];
+    for (int i = tid; i < kC3hLds / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
+    __syncthreads();
+
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int bands = kH / 4, steps = my_clips * bands;
+    const float half_inv_area = 0.5f / float(kH * width);
+    const int t_pos = tid >> 4, t_piece = tid & 15;                   // tile fetch role: (column, 16-byte piece of its record)
+
+    u32x4 pre[kT3Rows];
+    auto fetch = [&](int g) {            // tile of step g (clip g / 20, band g % 20) -> registers
+        const int k = g / bands, band = g - k * bands;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const char* src = reinterpret_cast<const char*>(in) + (clip * kH * kW) * 256 + tid * 16;
+#pragma unroll
+        for (int q = 0; q < kT3Rows; ++q) {
+            const int y = band * 4 - 1 + q;
+            const bool ok = y >= 0 && y < kH;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + int64_t(ok ? y : 0) * (kW * 256));
+            pre[q] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stash = [&](int g) {            // registers -> LDS tile g & 1
+        char* dst = ldsb + (g & 1) * kT3Bytes + (t_pos + 1) * kRec3 + t_piece * 16;
+#pragma unroll
+        for (int q = 0; q < kT3Rows; ++q) *reinterpret_cast<u32x4*>(dst + q * kRS * kRec3) = pre[q];
+    };
+
+    if (steps > 0) { fetch(0); stash(0); }
+    __syncthreads();
+    float pool = 0.f;
+    for (int g = 0; g < steps; ++g) {
+        const int k = g / bands, band = g - k * bands;
+        if (g + 1 < steps) fetch(g + 1);
+        const char* ap = ldsb + (g & 1) * kT3Bytes + pi * kRec3 + kq * 16;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][c][j] = 0.f;
+        // 72 fragment steps it = ((cb*3 + dx)*6 + q)*2 + ch, pipelined one step ahead
+        auto frag = [&](int it, int half) -> half8 {
+            const int cb = it / 36, dx = (it / 12) % 3, q = (it / 2) % 6, ch = it & 1;
+            return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + 16 * ch + dx) * kRec3 + half * 128 + cb * 64));
+        };
+        half8 ah = frag(0, 0), al = frag(0, 1);
+#pragma unroll
+        for (int it = 0; it < 72; ++it) {
+            half8 ahn = ah, aln = al;
+            if (it + 1 < 72) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
+            const int cb = it / 36, dx = (it / 12) % 3, q = (it / 2) % 6, ch = it & 1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = q - dy;
+                if (r < 0 || r > 3) continue;
+                const int ks = (cb * 3 + dx) * 3 + dy;
+                acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc[r][ch], 0, 0, 0);
+                acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[r][ch], 0, 0, 0);
+                acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[r][ch], 0, 0, 0);
+            }
+            ah = ahn; al = aln;
+        }
+        if (band == 0) pool = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = relu2(fmaf(acc[r][c][j], descale, bias));
+                    pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
+                }
+        if (band == bands - 1) {
+            float p2 = pool + __shfl_xor(pool, 16);
+            p2 += __shfl_xor(p2, 32);
+            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+            if (lane < 16) out[clip * 128 + 16 * nt + lane] = p2 * half_inv_area;
+        }
+        if (g + 1 < steps) stash(g + 1);     // the other buffer: last read in step g-1, retired by the barrier below
+        __syncthreads();
+    }
+}
+
 int64_t cnn_scratch_bytes(int64_t n, int n_conv) {
     return n_conv == 3 ? n * int64_t(kH) * 64 * kW * int64_t(sizeof(float)) : 0;
 }
@@ -887,16 +1021,31 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
         const char* e = getenv("WW_CNN_STRUCT");
         return (e && e[0] == 's') ? 1 : 2;
     }();
-    if (n_conv == 2 && split && h_struct == 2) {
+    if (split && h_struct == 2) {
         static bool a16 = false;
         if (!a16) {
-            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
             a16 = true;
         }
-        hipLaunchKernelGGL(cnn2h16_kernel, dim3(grid_h), dim3(768), kC2h16Lds, stream, mel, int(n), width,
+        if (n_conv == 2) {
+            hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid_h), dim3(768), kC2h16Lds, stream, mel, int(n), width,
+                               packed + L.conv1_w, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv1_h),
+                               reinterpret_cast<const u32x4*>(packed + L.conv2_h16),
+                               packed + L.conv2_hs, packed + L.conv2_b, pooled);
+            WW_HIP(hipGetLastError());
+            return WW_OK;
+        }
+        if (!scratch) return fail(WW_EINVAL, "n_conv == 3 needs ww_cnn_scratch_bytes() of scratch");
+        hipLaunchKernelGGL(cnn2h16_kernel<false>, dim3(grid_h), dim3(768), kC2h16Lds, stream, mel, int(n), width,
                            packed + L.conv1_w, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv1_h),
                            reinterpret_cast<const u32x4*>(packed + L.conv2_h16),
-                           packed + L.conv2_hs, packed + L.conv2_b, pooled);
+                           packed + L.conv2_hs, packed + L.conv2_b, static_cast<float*>(scratch));
+        WW_HIP(hipGetLastError());
+        hipLaunchKernelGGL(cnn3h_kernel, dim3(grid_h), dim3(512), kC3hLds, stream, static_cast<const _Float16*>(scratch), int(n),
+                           width, reinterpret_cast<const u32x4*>(packed + L.conv3_h), packed + L.conv3_hs, packed + L.conv3_b,
+                           pooled);
         WW_HIP(hipGetLastError());
         return WW_OK;
     }

@@ -80,6 +80,8 @@ struct PackedLayout {
     int64_t conv2_h;   // [2 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64 lanes][4 dwords = 8 f16]
     int64_t conv2_hs;  // [4]: 2^-S (descale applied to the f32 accumulator), S, 0, 0
     int64_t conv1_h;   // conv1 as a 32x32x16 f16 MFMA A operand: [hi,lo][64 lanes][4 dwords]; k = tap 0..8, k = 9: bias
+    int64_t conv3_h;   // (n_conv 3) conv3 split-precision B operands for 16x16x32: [8 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64][4]
+    int64_t conv3_hs;  // [4]: 2^-S3
     int64_t conv2_h16; // same weights for v_mfma_f32_16x16x32_f16: [4 ntile][9 kstep = dx*3+dy][hi,lo][64 lanes][4 dwords]
     int64_t total;
 };

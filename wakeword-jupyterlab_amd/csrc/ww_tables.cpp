@@ -137,6 +137,8 @@ PackedLayout packed_layout(int n_conv) {
     L.fc_b = take(4);
     L.conv2_h = take(2 * 18 * 2 * 64 * 4);
     L.conv2_hs = take(4);
+    L.conv3_h = n_conv == 3 ? take(8 * 18 * 2 * 64 * 4) : -1;
+    L.conv3_hs = n_conv == 3 ? take(4) : -1;
     L.conv1_h = take(2 * 64 * 4);
     L.conv2_h16 = take(4 * 9 * 2 * 64 * 4);
     L.total = o;
@@ -210,6 +212,40 @@ static float pack_conv2_f16x3(const float* w, float* out_words, float* out_words
                         o16b[base + 64 * 8 + lane * 8 + j] = lb;
                     }
             }
+    return std::ldexp(1.0f, -S);
+}
+
+// conv3 weight [128][64][3][3] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16:
+// k-step ks = (cb*3 + dx)*3 + dy covers input channels 32*cb .. 32*cb+31 of tap (dy, dx); lane (n = lane&15, kq = lane>>4)
+// holds B[k = 8kq + j][n] = W'[16*nt + n][32*cb + 8kq + j][dy][dx].  Returns the descale 2^-S.
+static float pack_conv3_f16x3(const float* w, float* out_words) {
+    float wmax = 0.f;
+    for (int i = 0; i < 128 * 64 * 9; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
+    int S = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) S = 12 - int(std::floor(std::log2(wmax)));
+    if (S > 24) S = 24;
+    if (S < -8) S = -8;
+    const float scale = std::ldexp(1.0f, S);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
+    for (int nt = 0; nt < 8; ++nt)
+        for (int cb = 0; cb < 2; ++cb)
+            for (int dx = 0; dx < 3; ++dx)
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int ks = (cb * 3 + dx) * 3 + dy;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 16 * nt + (lane & 15), ci = 32 * cb + 8 * (lane >> 4) + j;
+                            const float v = w[((co * 64 + ci) * 3 + dy) * 3 + dx] * scale;
+                            const _Float16 hi = static_cast<_Float16>(v);
+                            const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
+                            uint16_t hb, lb;
+                            std::memcpy(&hb, &hi, 2);
+                            std::memcpy(&lb, &lo, 2);
+                            const int64_t base = ((int64_t(nt) * 18 + ks) * 2) * 64 * 8;
+                            o16[base + lane * 8 + j] = hb;
+                            o16[base + 64 * 8 + lane * 8 + j] = lb;
+                        }
+                }
     return std::ldexp(1.0f, -S);
 }
 
@@ -299,6 +335,7 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     pack_lstm(sd->lstm_weight_ih[1], sd->lstm_bias_ih[1], sd->lstm_bias_hh[1], kHidden, out + L.l1_w, out + L.l1_b);
     std::memcpy(out + L.fc_w, sd->fc_weight, sizeof(float) * 2 * kHidden);
     std::memcpy(out + L.fc_b, sd->fc_bias, sizeof(float) * 2);
+    if (sd->n_conv == 3) out[L.conv3_hs] = pack_conv3_f16x3(sd->conv_weight[2], out + L.conv3_h);
     pack_conv1_f16x3(sd->conv_weight[0], sd->conv_bias[0], out + L.conv1_h);
     out[L.conv2_hs] = pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h, out + L.conv2_h16);
     return WW_OK;
