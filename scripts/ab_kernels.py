@@ -10,13 +10,15 @@ B = 4096
 pcm = torch.from_numpy(pkg.synth.make_clips_tiled(0, B, unique=64)).to(dev)
 mel = ops.logmel(pcm, True)
 packed = torch.from_numpy(ops.pack_state_dict(pkg.synth.make_state_dict("simple"))).to(dev)
-pooled = torch.empty(B, 64, device=dev); out = torch.empty_like(mel)
+pooled = ops.cnn_pool(mel, packed, 2); out = torch.empty_like(mel); lg = torch.empty(B, 2, device=dev)
 hs = []
 for path in libs:
     h = C.CDLL(path); h.ww_init(); hs.append(h)
 def run(h):
     if what == "logmel":
         rc = h.ww_logmel_f32(C.c_void_p(pcm.data_ptr()), C.c_int64(B), C.c_int64(16000), C.c_int64(16000), 1, C.c_void_p(out.data_ptr()), None)
+    elif what == "head":
+        rc = h.ww_lstm_fc_f32(C.c_void_p(pooled.data_ptr()), C.c_int64(B), C.c_void_p(packed.data_ptr()), 2, C.c_void_p(lg.data_ptr()), None)
     else:
         rc = h.ww_cnn_pool_f32(C.c_void_p(mel.data_ptr()), C.c_int64(B), 32, C.c_void_p(packed.data_ptr()), 2, None, C.c_void_p(pooled.data_ptr()), None)
     assert rc == 0, rc

@@ -270,14 +270,20 @@ static void pack_conv1_f16x3(const float* w, const float* b, float* out_words) {
         }
 }
 
-// weight_ih [4H][K] (gate rows i,f,g,o) -> [K][768], column (hb*3 + gate)*32 + u  <-  row goff[gate] + 32*hb + u
+// weight_ih [4H][K] (gate rows i,f,g,o) -> [K/8][768][8]: for every group of 8 consecutive k and every packed column
+// (column = (hb*3 + gate)*32 + u  <-  row goff[gate] + 32*hb + u) the 8 weights in the order k0,k2,k4,k6,k1,k3,k5,k7,
+// so that MFMA lane (n, kh) finds its B values of four consecutive 32x32x2 k-steps (k = 2s + kh) in ONE 16-byte load
+// and a wave's load covers 1 KiB contiguous.
 static void pack_lstm(const float* w_ih, const float* b_ih, const float* b_hh, int K, float* wt, float* b) {
     const int goff[3] = {0, 2 * kHidden, 3 * kHidden};   // i, g, o
     for (int hb = 0; hb < kHidden / 32; ++hb)
         for (int g = 0; g < 3; ++g)
             for (int u = 0; u < 32; ++u) {
                 const int col = (hb * 3 + g) * 32 + u, row = goff[g] + 32 * hb + u;
-                for (int k = 0; k < K; ++k) wt[int64_t(k) * kGateCols + col] = w_ih[int64_t(row) * K + k];
+                for (int k = 0; k < K; ++k) {
+                    const int kg = k >> 3, kk = k & 7, slot = (kk & 1) * 4 + (kk >> 1);
+                    wt[(int64_t(kg) * kGateCols + col) * 8 + slot] = w_ih[int64_t(row) * K + k];
+                }
                 b[col] = b_ih[row] + b_hh[row];
             }
 }
