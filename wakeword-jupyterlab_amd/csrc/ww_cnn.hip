@@ -705,41 +705,18 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[r][c][j] = 0.f;
-            // 36 fragment steps it = (dx*6 + q)*2 + ch, pipelined one step ahead
+            // 36 fragment steps it = (q*3 + dx)*2 + ch (input row outermost), pipelined one step ahead.  Output row r
+            // receives its last contribution with input row q = r + 2, so its bias/ReLU/pool (or store) epilogue is
+            // issued right there and runs under the MFMAs of the following input rows; only row 3's is left at the end.
             auto frag = [&](int it, int half) -> half8 {
-                const int dx = it / 12, q = (it / 2) % 6, ch = it & 1;
+                const int q = it / 6, dx = (it / 2) % 3, ch = it & 1;
                 return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + 16 * ch + dx) * kPos16 + half * 64));
             };
-            half8 ah = frag(0, 0), al = frag(0, 1);
-#ifdef WW_K2_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-            for (int it = 0; it < 36; ++it) {
-                half8 ahn = ah, aln = al;
-                if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
-                const int dx = it / 12, q = (it / 2) % 6, ch = it & 1;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int r = q - dy;
-                    if (r < 0 || r > 3) continue;
-                    const int ks = dx * 3 + dy;
-                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc[r][ch], 0, 0, 0);
-                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[r][ch], 0, 0, 0);
-                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[r][ch], 0, 0, 0);
-                }
-                ah = ahn; al = aln;
-            }
-#ifdef WW_K2_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            CSTAMP(1);
-            // D layout 16x16: lane&15 = channel, register j <-> position 16*ch + 4*(lane>>4) + j
-            if constexpr (!POOL) {
-                _Float16* o16 = reinterpret_cast<_Float16*>(out);
-                const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
+            if (band == 0) pool = 0.f;
+            auto epilogue_row = [&](int r) {
+                if constexpr (!POOL) {
+                    _Float16* o16 = reinterpret_cast<_Float16*>(out);
+                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -752,19 +729,12 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                             o16[rec] = hi;
                             o16[rec + 64] = static_cast<_Float16>(v - static_cast<float>(hi));
                         }
-            }
-            if (band == 0) pool = 0.f;
-            if constexpr (!POOL) {
-            } else if (width == kW) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
+                } else if (width == kW) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pool += relu2(fmaf(acc[r][c][j], descale, bias));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
+                } else {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -772,7 +742,27 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                             const float v = relu2(fmaf(acc[r][c][j], descale, bias));
                             pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
                         }
+                }
+            };
+            half8 ah = frag(0, 0), al = frag(0, 1);
+#pragma unroll
+            for (int it = 0; it < 36; ++it) {
+                half8 ahn = ah, aln = al;
+                if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
+                const int q = it / 6, dx = (it / 2) % 3, ch = it & 1;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = q - dy;
+                    if (r < 0 || r > 3) continue;
+                    const int ks = dx * 3 + dy;
+                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc[r][ch], 0, 0, 0);
+                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[r][ch], 0, 0, 0);
+                    acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[r][ch], 0, 0, 0);
+                }
+                ah = ahn; al = aln;
+                if (it % 6 == 5 && q >= 2) epilogue_row(q - 2);
             }
+            CSTAMP(1);
             if (POOL && band == kH / kBand - 1) {
                 float p2 = pool + __shfl_xor(pool, 16);
                 p2 += __shfl_xor(p2, 32);
