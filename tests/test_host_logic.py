@@ -56,6 +56,19 @@ def test_checkpoint_round_trip(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
 
 
+def test_deployment_package_layout_round_trips(tmp_path):
+    from wakeword_jupyterlab_amd.model import load_checkpoint, save_deployment_package
+    m = pkg.WakewordModel()
+    path = os.path.join(tmp_path, "wakeword_deployment_model.pth")
+    d = save_deployment_package(m, path, best_val_accuracy=98.93, epoch=42, device="cpu")
+    assert set(d) == {"model_state_dict", "model_config", "audio_config", "training_info", "classes"}       # notebook cell 21
+    assert d["classes"] == ["negative", "wakeword"] and d["model_config"]["DROPOUT"] == 0.6 and d["audio_config"]["N_FFT"] == 2048
+    m2 = pkg.WakewordModel()
+    ckpt = load_checkpoint(m2, path, map_location="cpu")                       # weights_only=True load
+    assert ckpt["training_info"]["epoch"] == 42
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
 def test_unsupported_configurations_are_refused():
     class Cfg(AudioConfig):
         N_FFT = 1024

@@ -70,17 +70,17 @@ def test_packed_weight_image_layout(arch):
         want = w.reshape(cout // 32, 32, cin // 2, 2, 3, 3).transpose(0, 2, 4, 5, 3, 1)
         assert np.array_equal(wb, want)
         assert np.array_equal(take(cout), sd[f"conv{li}.bias"])
-    # LSTM: [K/8][768][8]; column (hb*3 + g)*32 + u <- row goff[g] + 32*hb + u, gates (i, g, o) = rows 0, 512, 768;
-    # inside a group of 8 consecutive k the order is k0,k2,k4,k6,k1,k3,k5,k7
-    order = np.array([0, 2, 4, 6, 1, 3, 5, 7])
+    # LSTM: [K/16][768][16]; column (hb*3 + g)*32 + u <- row goff[g] + 32*hb + u, gates (i, g, o) = rows 0, 512, 768;
+    # inside a group of 16 consecutive k the order is by (k mod 4, k div 4): 0,4,8,12,1,5,9,13,...
+    order = np.array([4 * (s % 4) + s // 4 for s in range(16)])
     for layer, K in enumerate([64 if arch == "simple" else 128, 256]):
-        wt = take(K * 768).reshape(K // 8, 8, 3, 32, 8)              # [kg][hb][gate][u][slot]
+        wt = take(K * 768).reshape(K // 16, 8, 3, 32, 16)            # [kg][hb][gate][u][slot]
         b = take(768).reshape(8, 3, 32)
         w_ih = sd[f"lstm.weight_ih_l{layer}"]
         bias = sd[f"lstm.bias_ih_l{layer}"] + sd[f"lstm.bias_hh_l{layer}"]
         for g, off in enumerate([0, 512, 768]):
             rows = (off + 32 * np.arange(8)[:, None] + np.arange(32)[None]).reshape(-1)           # [hb*32 + u]
-            want = w_ih[rows].reshape(8, 32, K // 8, 8)[:, :, :, order].transpose(2, 0, 1, 3)      # [kg][hb][u][slot]
+            want = w_ih[rows].reshape(8, 32, K // 16, 16)[:, :, :, order].transpose(2, 0, 1, 3)    # [kg][hb][u][slot]
             assert np.array_equal(wt[:, :, g], want)
             assert np.array_equal(b[:, g, :].reshape(-1), bias[rows])
     assert np.array_equal(take(512), sd["fc.weight"].reshape(-1))

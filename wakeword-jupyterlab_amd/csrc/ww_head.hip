@@ -6,14 +6,13 @@
 //     g = W_ih x + (b_ih + b_hh);  c = sigmoid(g_i) * tanh(g_g);  h = sigmoid(g_o) * tanh(c)
 // so the gate GEMM is [clips, K] x [K, 768] (i, g, o columns; the forget gate and W_hh are dead).
 //
-// One 8-wave workgroup per 32 clips.  Wave w owns hidden units 32w..32w+31: three 32x32 f32-MFMA tiles
-// (i, g, o) that share the A operand, so the gate non-linearity runs in registers on matching layouts.
-// Layer-0 output goes to LDS and is layer 1's A operand; weights stream from L2 as B operands.
+// One 8-wave workgroup per 16 clips (256 workgroups at 4096 clips: every CU busy).  Wave w owns hidden units 32w..32w+31:
+// six 16x16 f32-MFMA tiles (gates i, g, o x two halves) that share the A operand, so the gate non-linearity runs in
+// registers on matching layouts.  Layer-0 output goes to LDS and is layer 1's A operand; weights stream from L2.
 #include "ww_internal.h"
 
 namespace ww {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kHS = kHidden + 4;   // LDS row stride for [32 clips][256]: 16-byte aligned rows, 4 banks apart
 
@@ -31,58 +30,68 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 #endif
 
-// LDS activation rows use the same within-8 permutation as the packed weights: element k of a row sits at
-// 8*(k>>3) + slot8(k), slot8 = (k&1)*4 + ((k&7)>>1), so that lane (clip, kh) reads its A values of four
-// consecutive k-steps with ONE ds_read_b128.
-__device__ __forceinline__ int perm8(int k) { return (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1); }
+// LDS activation rows use the same within-16 permutation as the packed weights: element k of a row sits at
+// 16*(k>>4) + slot16(k), slot16 = (k&3)*4 + ((k&15)>>2), so that lane (clip, kq) reads its A values of four
+// consecutive k-steps (k = 4s + kq) with ONE ds_read_b128.
+__device__ __forceinline__ int perm16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k & 15) >> 2); }
 
-// xs: LDS [32][xstride] activations (row = clip, permuted); wt: packed [K/8][768][8]; hb = this wave's hidden block.
-// Writes h[clip][perm8(32*hb + u)] into hout (LDS, stride kHS4).  Weight loads run two 8-k groups ahead of the MFMAs.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kClipsPerBlock = 16;
+
+// xs: LDS [16][xstride] activations (row = clip, permuted); wt: packed [K/16][768][16]; hb = this wave's hidden block of
+// 32 units = six 16x16 tiles (gate i,g,o x two halves).  Writes h[clip][perm16(32*hb + u)] into hout.
+// Weight loads run two 16-k groups ahead of the MFMAs.
 template <int K>
 __device__ __forceinline__ void lstm_layer(const float* __restrict__ xs, int xstride, const float* __restrict__ wt,
                                            const float* __restrict__ bias, int hb, int lane, float* __restrict__ hout,
                                            int hstride) {
-    const int row = lane & 31, kh = lane >> 5;
-    f32x16 acc[3];
+    const int col = lane & 15, kq = lane >> 4;
+    f32x4 acc[3][2];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[g][j] = 0.f;
-    const float4* a_p = reinterpret_cast<const float4*>(xs + row * xstride + kh * 4);
-    const float4* b_p = reinterpret_cast<const float4*>(wt + (int64_t(hb) * 96 + row) * 8 + kh * 4);
-    constexpr int G = K / 8, D = 2;                  // groups, prefetch depth
-    float4 bw[D][3];
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][h][j] = 0.f;
+    const float4* a_p = reinterpret_cast<const float4*>(xs + col * xstride + kq * 4);
+    const float4* b_p = reinterpret_cast<const float4*>(wt + (int64_t(hb) * 96 + col) * 16 + kq * 4);
+    constexpr int G = K / 16, D = 2;                 // 16-k groups, prefetch depth
+    float4 bw[D][6];
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int g = 0; g < 3; ++g) bw[d][g] = b_p[(int64_t(d) * kGateCols + 32 * g) * 2];
+        for (int t = 0; t < 6; ++t) bw[d][t] = b_p[(int64_t(d) * kGateCols + 16 * t) * 4];
 #pragma unroll
     for (int kg = 0; kg < G; ++kg) {
-        const float4 a = a_p[kg * 2];
-        float4 bc[3];
+        const float4 a = a_p[kg * 4];
+        float4 bc[6];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) bc[g] = bw[kg % D][g];
+        for (int t = 0; t < 6; ++t) bc[t] = bw[kg % D][t];
         if (kg + D < G) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) bw[kg % D][g] = b_p[(int64_t(kg + D) * kGateCols + 32 * g) * 2];
+            for (int t = 0; t < 6; ++t) bw[kg % D][t] = b_p[(int64_t(kg + D) * kGateCols + 16 * t) * 4];
         }
         const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                const float bv = s == 0 ? bc[g].x : s == 1 ? bc[g].y : s == 2 ? bc[g].z : bc[g].w;
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[g], 0, 0, 0);
+            for (int t = 0; t < 6; ++t) {              // tile t = gate*2 + half: packed columns 32*gate + 16*half ..
+                const float bv = s == 0 ? bc[t].x : s == 1 ? bc[t].y : s == 2 ? bc[t].z : bc[t].w;
+                acc[t >> 1][t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[t >> 1][t & 1], 0, 0, 0);
             }
     }
-    // D: lane&31 = hidden unit u, register j <-> clip (j&3) + 8*(j>>2) + 4*(lane>>5)
-    const float b_i = bias[hb * 96 + row], b_g = bias[hb * 96 + 32 + row], b_o = bias[hb * 96 + 64 + row];
-    const int ucol = perm8(32 * hb + row);
+    // D: lane&15 = hidden unit within the half, register j <-> clip 4*(lane>>4) + j
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int clip = (j & 3) + 8 * (j >> 2) + 4 * kh;
-        const float c = sigmoidf_(acc[0][j] + b_i) * tanhf_(acc[1][j] + b_g);
-        hout[clip * hstride + ucol] = sigmoidf_(acc[2][j] + b_o) * tanhf_(c);
+    for (int h = 0; h < 2; ++h) {
+        const int u = 16 * h + col;
+        const float b_i = bias[hb * 96 + u], b_g = bias[hb * 96 + 32 + u], b_o = bias[hb * 96 + 64 + u];
+        const int ucol = perm16(32 * hb + u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int clip = 4 * kq + j;
+            const float c = sigmoidf_(acc[0][h][j] + b_i) * tanhf_(acc[1][h][j] + b_g);
+            hout[clip * hstride + ucol] = sigmoidf_(acc[2][h][j] + b_o) * tanhf_(c);
+        }
     }
 }
 
@@ -91,17 +100,17 @@ __global__ __launch_bounds__(512) void lstm_fc_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ fcw, const float* __restrict__ fcb,
                                                       float* __restrict__ logits, float* __restrict__ prob) {
-    __shared__ __attribute__((aligned(16))) float xs[32 * 132];
-    __shared__ __attribute__((aligned(16))) float h0[32 * kHS];
-    __shared__ __attribute__((aligned(16))) float h1[32 * kHS];
+    __shared__ __attribute__((aligned(16))) float xs[kClipsPerBlock * 132];
+    __shared__ __attribute__((aligned(16))) float h0[kClipsPerBlock * kHS];
+    __shared__ __attribute__((aligned(16))) float h1[kClipsPerBlock * kHS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int clip0 = blockIdx.x * 32;
+    const int clip0 = blockIdx.x * kClipsPerBlock;
     const int xstride = C + 4;
 
-    for (int i = tid; i < 32 * C; i += 512) {
+    for (int i = tid; i < kClipsPerBlock * C; i += 512) {
         const int r = i / C, k = i - r * C;
-        xs[r * xstride + perm8(k)] = (clip0 + r < n) ? pooled[int64_t(clip0 + r) * C + k] : 0.f;
+        xs[r * xstride + perm16(k)] = (clip0 + r < n) ? pooled[int64_t(clip0 + r) * C + k] : 0.f;
     }
     __syncthreads();
     if (C == 64) lstm_layer<64>(xs, xstride, w0, b0, wave, lane, h0, kHS);
@@ -110,18 +119,19 @@ __global__ __launch_bounds__(512) void lstm_fc_kernel(const float* __restrict__ 
     lstm_layer<kHidden>(h0, kHS, w1, b1, wave, lane, h1, kHS);
     __syncthreads();
     {
-        // fc: 64 outputs (32 clips x 2 classes), each a 256-term dot product split over 8 lanes, summed in fixed order
-        const int o = tid >> 3, part = tid & 7, clip = o >> 1, cls = o & 1;
+        // fc: 32 outputs (16 clips x 2 classes), each a 256-term dot product split over 16 lanes, summed in fixed order
+        const int o = tid >> 4, part = tid & 15, clip = o >> 1, cls = o & 1;
         const float* hrow = h1 + clip * kHS;
         const float* wrow = fcw + cls * kHidden;
         float acc = 0.f;
 #pragma unroll 8
-        for (int k = part * 32; k < part * 32 + 32; ++k) acc = fmaf(hrow[perm8(k)], wrow[k], acc);
+        for (int k = part * 16; k < part * 16 + 16; ++k) acc = fmaf(hrow[perm16(k)], wrow[k], acc);
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
         acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 8);
         const float logit = acc + fcb[cls];
-        const float other = __shfl_xor(logit, 8);          // the other class of the same clip
+        const float other = __shfl_xor(logit, 16);         // the other class of the same clip
         if (part == 0 && clip0 + clip < n) {
             logits[int64_t(clip0 + clip) * 2 + cls] = logit;
             if (prob && cls == 1) prob[clip0 + clip] = 1.0f / (1.0f + expf(other - logit));   // softmax(logits)[1]
@@ -133,7 +143,7 @@ int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_co
                    hipStream_t stream) {
     if (n == 0) return WW_OK;
     const PackedLayout L = packed_layout(n_conv);
-    const int grid = int((n + 31) / 32);
+    const int grid = int((n + kClipsPerBlock - 1) / kClipsPerBlock);
     hipLaunchKernelGGL(lstm_fc_kernel, dim3(grid), dim3(512), 0, stream, pooled, int(n), L.c_last, packed + L.l0_w,
                        packed + L.l0_b, packed + L.l1_w, packed + L.l1_b, packed + L.fc_w, packed + L.fc_b, logits,
                        prob);

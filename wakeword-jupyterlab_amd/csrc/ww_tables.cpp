@@ -270,10 +270,10 @@ static void pack_conv1_f16x3(const float* w, const float* b, float* out_words) {
         }
 }
 
-// weight_ih [4H][K] (gate rows i,f,g,o) -> [K/8][768][8]: for every group of 8 consecutive k and every packed column
-// (column = (hb*3 + gate)*32 + u  <-  row goff[gate] + 32*hb + u) the 8 weights in the order k0,k2,k4,k6,k1,k3,k5,k7,
-// so that MFMA lane (n, kh) finds its B values of four consecutive 32x32x2 k-steps (k = 2s + kh) in ONE 16-byte load
-// and a wave's load covers 1 KiB contiguous.
+// weight_ih [4H][K] (gate rows i,f,g,o) -> [K/16][768][16]: for every group of 16 consecutive k and every packed column
+// (column = (hb*3 + gate)*32 + u  <-  row goff[gate] + 32*hb + u) the 16 weights ordered by (k mod 4, k div 4),
+// so that lane (n, kq) of a 16x16x4 f32 MFMA finds its B values of four consecutive k-steps (k = 4s + kq) in ONE
+// 16-byte load and a wave's load covers 1 KiB contiguous.
 static void pack_lstm(const float* w_ih, const float* b_ih, const float* b_hh, int K, float* wt, float* b) {
     const int goff[3] = {0, 2 * kHidden, 3 * kHidden};   // i, g, o
     for (int hb = 0; hb < kHidden / 32; ++hb)
@@ -281,8 +281,8 @@ static void pack_lstm(const float* w_ih, const float* b_ih, const float* b_hh, i
             for (int u = 0; u < 32; ++u) {
                 const int col = (hb * 3 + g) * 32 + u, row = goff[g] + 32 * hb + u;
                 for (int k = 0; k < K; ++k) {
-                    const int kg = k >> 3, kk = k & 7, slot = (kk & 1) * 4 + (kk >> 1);
-                    wt[(int64_t(kg) * kGateCols + col) * 8 + slot] = w_ih[int64_t(row) * K + k];
+                    const int kg = k >> 4, kk = k & 15, slot = (kk & 3) * 4 + (kk >> 2);
+                    wt[(int64_t(kg) * kGateCols + col) * 16 + slot] = w_ih[int64_t(row) * K + k];
                 }
                 b[col] = b_ih[row] + b_hh[row];
             }

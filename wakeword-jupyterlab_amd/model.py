@@ -90,3 +90,18 @@ def load_checkpoint(model: nn.Module, path: str, map_location=None):
     sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
     model.load_state_dict(sd)
     return ckpt
+
+
+def save_deployment_package(model: nn.Module, path: str, best_val_accuracy=0, epoch=0, device="cuda"):
+    """Write the reference's deployment dict (notebook cell 21, wakeword_training.ipynb:951-977): model_state_dict,
+    model_config, audio_config, training_info, classes.  Loadable by the reference and by `load_checkpoint`."""
+    pkg = {
+        "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+        "model_config": {"HIDDEN_SIZE": ModelConfig.HIDDEN_SIZE, "NUM_LAYERS": ModelConfig.NUM_LAYERS,
+                         "DROPOUT": float(model.dropout.p), "NUM_CLASSES": ModelConfig.NUM_CLASSES},
+        "audio_config": {k: getattr(AudioConfig, k) for k in ("SAMPLE_RATE", "DURATION", "N_MELS", "N_FFT", "HOP_LENGTH", "FMIN", "FMAX")},
+        "training_info": {"best_val_accuracy": best_val_accuracy, "epoch": epoch, "device": str(device)},
+        "classes": ["negative", "wakeword"],
+    }
+    torch.save(pkg, path)
+    return pkg
