@@ -1,22 +1,27 @@
-// K2: Conv2d(3x3, pad 1)+ReLU stack + global average pool on the f32 matrix cores.
+// K2: Conv2d(3x3, pad 1)+ReLU stack + global average pool on the matrix cores.
 //
 // Replaces `F.relu(conv1) -> F.relu(conv2) [-> F.relu(conv3)] -> AdaptiveAvgPool2d((1,1))`
 // (/root/reference/wakeword_training/train_wakeword.py:39-41,
 //  /root/reference/wakeword_training_script.py:170-173).
 //
-// conv2 (32->64, 94.4 of the model's 96.5 MFLOP per clip) and conv3 (64->128) run as implicit GEMMs on
-// v_mfma_f32_32x32x2_f32 (exact f32, bit-for-bit an fmaf chain):
-//     M = the 32 columns of one image row   (A operand: activations, lane = column)
-//     N = 32 output channels                (B operand: weights, lane = channel)
-//     K = (input-channel pair, dy, dx)      2 channels per instruction
-// * the weights of a wave's N-tile (144 B-operand registers) are loaded ONCE per persistent workgroup
-//   and stay in VGPRs for every clip it processes: no weight re-reads at all;
-// * activations are read from an LDS tile [ci][row][34] with one ds_read_b32 per A register, and a
-//   register is reused for every (output row, dy) pair that touches its input row (6 reads feed 12 MFMAs);
-// * conv1 (1->32, 1.5 MFLOP) is recomputed per 8-row band on the VALU straight into that LDS tile, so
-//   conv1's 327 KB/clip output never exists in HBM;  bias+ReLU+pool are fused into the MFMA epilogue.
+// conv2 (32->64, 94.4 of the model's 96.5 MFLOP per clip) and conv3 (64->128) are implicit GEMMs:
+//     M = columns of one image row, N = output channels, K = (input channel, dy, dx).
+// Two arithmetics, selected process-wide (ww_set_conv_math; both parity-tested on every GPU test):
 //
-// Algorithmic flops per clip (T = 32): conv1 1,474,560 + conv2 94,371,840.
+//   f16x3 (default)  cnn2h16_kernel<POOL> [+ cnn3h_kernel]: every fp32 operand as two f16 halves, three
+//                    v_mfma_f32_16x16x32_f16 per product block, fp32 accumulate (~2^-21 relative).  12-wave workgroup:
+//                    8 consumer waves (2 per SIMD) + 4 producer waves that run conv1 -- itself an MFMA -- one band ahead
+//                    into a double-buffered LDS tile.  (cnn2h_kernel: the earlier 8-wave 32x32x16 form, WW_CNN_STRUCT=spec.)
+//   f32              cnn2_kernel<POOL> [+ cnn3_kernel]: v_mfma_f32_32x32x2_f32, exact fp32 (bit-for-bit an fmaf chain);
+//                    conv1 on the VALU per band.
+//
+// Common to all: the weights of a wave's N-tile stay in VGPRs for every clip a persistent workgroup processes (no weight
+// re-reads); an activation fragment read from LDS is reused for every (output row, dy) pair that touches its input
+// row; conv1's 327 KB/clip output never exists in HBM; bias + ReLU + pool are fused into the MFMA epilogue with
+// fixed-order reductions (deterministic, NaN-propagating like torch).
+//
+// Algorithmic flops per clip (T = 32): conv1 1,474,560 + conv2 94,371,840 [+ conv3 377,487,360].
+// Diagnostic build: -DWW_STAMPS adds s_memtime phase stamps (never in the shipped library).
 #include <cstdlib>
 
 #include "ww_internal.h"
@@ -362,11 +367,6 @@ __global__ __launch_bounds__(512, 2) void cnn2h_kernel(const float* __restrict__
                 return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + dx) * kPosBytes + cb * 32 + half * 64));
             };
             half8 ah = frag(0, 0), al = frag(0, 1);
-#ifdef WW_ABL_NO_MFMA
-#pragma unroll
-            for (int ks = 0; ks < 18; ++ks) { asm volatile("" :: "v"(bh[ks]), "v"(bl[ks])); }
-            acc[0][0] = float(ah[0]) + float(al[0]);
-#else
 #pragma unroll
             for (int it = 0; it < 36; ++it) {
                 half8 ahn = ah, aln = al;
@@ -383,7 +383,6 @@ __global__ __launch_bounds__(512, 2) void cnn2h_kernel(const float* __restrict__
                 }
                 ah = ahn; al = aln;
             }
-#endif
             const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
             if constexpr (POOL) {
                 if (band == 0) pool = 0.f;
@@ -417,9 +416,7 @@ __global__ __launch_bounds__(512, 2) void cnn2h_kernel(const float* __restrict__
                 }
             }
         } else if (g + 1 < steps) {
-#ifndef WW_ABL_NO_CONV1
             produce(g + 1);
-#endif
             const int k1 = (g + 1) / (kH / kBand);
             if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);   // two clips ahead of the MFMAs
         }
@@ -579,24 +576,15 @@ __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh,
     conv1_row_gather(r0, mh, ml, y0 - 1 + pw, x, h);
     conv1_row_gather(r1, mh, ml, y0 - 1 + pw + 4, x, h);
     if (third) conv1_row_gather(r2, mh, ml, y0 - 1 + pw + 8, x, h);
-#ifdef WW_ABL_P_NOMFMA
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { r0.acc[j] = float(r0.ph[j & 7]); r1.acc[j] = float(r1.pl[j & 7]); r2.acc[j] = float(r2.ph[j & 7]); }
-#else
     conv1_row_mfma(r0, a1h, a1l);
     conv1_row_mfma(r1, a1h, a1l);
     if (third) conv1_row_mfma(r2, a1h, a1l);
-#endif
     char* rec = act + (pw * kRS + x + 1) * kPos16 + h * 32;            // this lane's 16 channels 16h..16h+15
     const bool col_ok = x < width;
     // rows outside the image are conv2's zero padding: `keep` false zeroes them (never `full` for such a row)
-#ifdef WW_ABL_P_NOSTORE
-    if (r0.acc[0] + r1.acc[1] + (third ? r2.acc[2] : 0.f) == 12345.678f) *reinterpret_cast<float*>(rec) = 1.f;
-#else
     conv1_row_store(r0, rec, col_ok && r0.ok, full && r0.ok);
     conv1_row_store(r1, rec + 4 * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
     if (third) conv1_row_store(r2, rec + 8 * kRS * kPos16, col_ok && r2.ok, full && r2.ok);
-#endif
 }
 
 #ifdef WW_STAMPS
@@ -642,12 +630,10 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     if (!consumer) {
         a1h = __builtin_bit_cast(half8, w1H[lane]);
         a1l = __builtin_bit_cast(half8, w1H[64 + lane]);
-#ifndef WW_K2_NO_PRODPRIO
         // The producers are VALU streams sharing each SIMD's issue port with two MFMA streams (an MFMA holds the port
         // for 8 of its 16 cycles); issue is arbitrated by priority, then age.  Without this the producers starve and
         // the consumers wait a third of the time at the band barrier.
         __builtin_amdgcn_s_setprio(3);
-#endif
     }
     for (int i = tid; i < kC2h16Lds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
     __syncthreads();
@@ -770,9 +756,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             }
             CSTAMP(2);
         } else if (g + 1 < steps) {
-#ifndef WW_ABL_P_NONE
             produce(g + 1);
-#endif
             const int k1 = (g + 1) / (kH / kBand);
             if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);
             CSTAMP(3);
