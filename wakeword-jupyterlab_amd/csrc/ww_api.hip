@@ -125,7 +125,7 @@ struct ww_streamer {
     const float* packed;
     hipStream_t stream;
     float* ring;         // [n_mics][16000]
-    int32_t* pos;        // device: index of the oldest sample (== next write position)
+    int32_t* pos;        // device: [0] index of the oldest sample (== next write position), [1] append-kernel ticket
     void* workspace;
     hipGraph_t graph;
     hipGraphExec_t exec;
@@ -135,19 +135,26 @@ struct ww_streamer {
     float* own_logits;   // used when the caller passes logits_dev == NULL
 };
 
-__global__ void ring_append_kernel(float* __restrict__ ring, const int32_t* __restrict__ pos_p,
+// Append one hop to every microphone's ring and THEN advance the shared ring position, in one launch: every workgroup
+// reads `pos` before it writes samples and takes a ticket after; the workgroup that draws the last ticket knows all
+// others are past their read of `pos` and publishes pos + hop for the kernels that follow in the graph.
+__global__ void ring_append_kernel(float* __restrict__ ring, int32_t* __restrict__ pos_p, uint32_t* __restrict__ ticket,
                                    const float* __restrict__ hop, int n_mics, int hop_len) {
-    const int pos = *pos_p;
+    const int pos = *reinterpret_cast<volatile int32_t*>(pos_p);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_mics * hop_len; i += gridDim.x * blockDim.x) {
         const int m = i / hop_len, k = i - m * hop_len;
         int at = pos + k;
         if (at >= kClip) at -= kClip;
         ring[int64_t(m) * kClip + at] = hop[i];
     }
-}
-__global__ void ring_advance_kernel(int32_t* pos_p, int hop_len) {
-    int p = *pos_p + hop_len;
-    *pos_p = p >= kClip ? p - kClip : p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1) {     // wraps to 0: ready for the next replay
+            const int p = pos + hop_len;
+            *pos_p = p >= kClip ? p - kClip : p;
+        }
+    }
 }
 __global__ void ring_unroll_kernel(const float* __restrict__ ring, const int32_t* __restrict__ pos_p,
                                    float* __restrict__ out, int n_mics) {
@@ -164,8 +171,8 @@ __global__ void ring_unroll_kernel(const float* __restrict__ ring, const int32_t
 static int streamer_enqueue(ww_streamer* s, const float* hop_dev, float* prob_dev, float* logits_dev) {
     const int threads = 256;
     const int blocks = (s->n_mics * s->hop + threads - 1) / threads;
-    hipLaunchKernelGGL(ring_append_kernel, dim3(blocks), dim3(threads), 0, s->stream, s->ring, s->pos, hop_dev, s->n_mics, s->hop);
-    hipLaunchKernelGGL(ring_advance_kernel, dim3(1), dim3(1), 0, s->stream, s->pos, s->hop);
+    hipLaunchKernelGGL(ring_append_kernel, dim3(blocks), dim3(threads), 0, s->stream, s->ring, s->pos,
+                       reinterpret_cast<uint32_t*>(s->pos + 1), hop_dev, s->n_mics, s->hop);
     WW_HIP(hipGetLastError());
     Workspace w = carve(s->workspace, s->n_mics, s->n_conv);
     if (int rc = launch_logmel(s->ring, s->n_mics, kClip, kClip, 1, s->pos, kClip, w.logmel, s->stream)) return rc;
