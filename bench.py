@@ -103,7 +103,12 @@ def main():
     import wakeword_jupyterlab_amd as pkg
     from wakeword_jupyterlab_amd import distributed as wdist
 
-    rank, world, local = wdist.init_from_env("nccl")
+    # WW_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share GPUs, the logits
+    # all-gather goes through host memory); the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("WW_BENCH_BACKEND", "nccl")
+    rank, world, local = wdist.init_from_env(backend)
+    if backend == "gloo" and torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -150,7 +155,12 @@ def main():
         nat.check(nat.lib.ww_lstm_fc_f32(p(pooled), B, p(packed), n_conv, p(logits), st))
         if ev: ev[3].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, logits)
+            if backend == "gloo":
+                parts = [torch.empty((B, 2)) for _ in range(world)]
+                dist.all_gather(parts, logits.cpu())
+                gathered.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(gathered, logits)
 
     def fence():
         if world > 1:
@@ -167,7 +177,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -202,9 +212,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[2]: batch={B} 1 s/16 kHz clips per GPU, full log-mel + CNN + LSTM HIP forward "
-                            f"(K1 -> K2 -> K3{' -> RCCL all-gather of logits' if world > 1 else ''}), PCM and logits resident in HBM",
-                "model": "SimpleWakewordModel (train_wakeword.py:28-49), random-init weights seed 1234" if args.arch == "simple"
-                         else "WakewordModel 3-conv (wakeword_training_script.py:141-184), random-init weights seed 1234",
+                            f"(K1 -> K2 -> K3{' -> RCCL all-gather of logits' if world > 1 else ''}), PCM and logits resident in HBM; "
+                            + ("SimpleWakewordModel (train_wakeword.py:28-49)" if args.arch == "simple"
+                               else "3-conv WakewordModel (wakeword_training_script.py:141-184)") + ", random-init weights seed 1234",
                 "global_batch": world * B, "clips_per_gpu": B, "conv_math": conv_math,
                 "parallelism": f"clips sharded over {world} GPU(s), replicated weights",
             },
