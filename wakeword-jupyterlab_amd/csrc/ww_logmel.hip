@@ -112,41 +112,27 @@ __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Eight float4 loads of one frame (samples base + 256*n1 .. +3).  ALIGNED (clip_len % 4 == 0, which includes the
-// 16000-sample case and the streaming ring): every float4 is wholly inside or wholly outside the clip, so the loads
-// are branch-free -- clamped address + select -- and all eight stay in flight together.  Otherwise a float4 can
-// straddle clip_len and the tail is fetched element-wise (rare: ragged clip lengths).
-template <bool ALIGNED>
-__device__ __forceinline__ unsigned load_frame(float4 (&sn)[8], const float* __restrict__ clip, int base, int clip_len,
-                                               bool ring, int ring_pos, int ring_len) {
-    // Returns a bit mask of the float4s that lie inside the clip; the caller zeroes the others WHEN IT USES the data,
-    // so that nothing here consumes a loaded value and the eight loads stay asynchronous.
-    unsigned okmask = 0;
+// Eight 16-byte loads of one frame (samples base + 256*n1 .. +3) through a buffer descriptor whose range is exactly the
+// clip: the hardware returns 0 for every dword outside [0, clip_len) -- the STFT's centre padding, the right zero-pad
+// of short clips and "no next clip" (a zero-record descriptor) cost no compare, select or branch, and the eight loads
+// stay in flight together.  Everything goes into the per-lane offset: the scalar offset of a buffer instruction is not
+// range-checked.  Ring mode (streaming): sample i of the window lives at (pos + i) mod len.
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned int;
+
+template <bool RING>
+__device__ __forceinline__ void load_frame(float4 (&sn)[8], __amdgpu_buffer_rsrc_t rsrc, int base, int ring_pos, int ring_len) {
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
-        const int idx = base + 256 * n1;              // multiple of 4
-        if constexpr (ALIGNED) {
-            const bool ok = idx >= 0 && idx < clip_len;
-            int at = ok ? idx : 0;
-            if (ring) { at += ring_pos; at = at >= ring_len ? at - ring_len : at; }
-            sn[n1] = *reinterpret_cast<const float4*>(clip + at);
-            okmask |= ok ? (1u << n1) : 0u;
-        } else {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx >= 0 && idx < clip_len) {
-                if (idx + 4 <= clip_len) {
-                    x = *reinterpret_cast<const float4*>(clip + idx);
-                } else {
-                    x.x = clip[idx];
-                    if (idx + 1 < clip_len) x.y = clip[idx + 1];
-                    if (idx + 2 < clip_len) x.z = clip[idx + 2];
-                }
-            }
-            sn[n1] = x;
-            okmask |= 1u << n1;
+        const int idx = base + 256 * n1;              // multiple of 4; may be negative or past the end
+        int off = idx * 4;
+        if constexpr (RING) {
+            int at = idx + ring_pos;
+            at = at >= ring_len ? at - ring_len : at;
+            off = (idx >= 0 && idx < ring_len) ? at * 4 : -1;
         }
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        sn[n1] = __builtin_bit_cast(float4, v);
     }
-    return okmask;
 }
 
 #ifdef WW_STAMPS
@@ -157,7 +143,7 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do {} while (0)
 #endif
 
-template <bool ALIGNED>
+template <bool RING>
 __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
                                                              int clip_len, int n_clips, int normalize,
                                                              const int32_t* __restrict__ ring_pos_p, int ring_len,
@@ -208,8 +194,7 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
     for (int i = tid; i < 7 * 128 * 2; i += kThreads) lds[kOffTw1 + i] = (&tb->tw1[0][0].x)[i];
     for (int i = tid; i < kNfft; i += kThreads) lds[kOffWin + i] = tb->window[i];
 #endif
-    const int ring_pos = ring_pos_p ? *ring_pos_p : 0;
-    const bool ring = ring_pos_p != nullptr;
+    const int ring_pos = RING ? *ring_pos_p : 0;
     __syncthreads();
     // this lane's filters in the per-frame combine: f = lane and f = lane + 64 (< 80)
     const int my_p0a = fp0[lane], my_cnta = fcnt[lane];
@@ -228,18 +213,19 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
 
     // the samples of a frame are fetched one frame ahead (8 x dwordx4 per lane in flight under the FFT); the chain runs
     // across clip boundaries, so only the very first frame of a workgroup is loaded synchronously
+    const unsigned clip_bytes = unsigned(clip_len) * 4u;
+    auto clip_rsrc = [&](int c) {        // descriptor of clip c, or an empty one past the end: all-zero loads
+        const bool ok = c < n_clips;
+        const float* base = pcm + int64_t(ok ? c : 0) * clip_stride;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, ok ? clip_bytes : 0u, 0x00020000);
+    };
     float4 sn[8];
-    unsigned okmask = 0;
-    if (int(blockIdx.x) < n_clips)
-        okmask = load_frame<ALIGNED>(sn, pcm + int64_t(blockIdx.x) * clip_stride, wave * kHop - kNfft / 2 + 4 * lane, clip_len,
-                                     ring, ring_pos, ring_len);
+    load_frame<RING>(sn, clip_rsrc(blockIdx.x), wave * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
 #pragma unroll 1
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
-        const float* __restrict__ x = pcm + int64_t(clip) * clip_stride;
-        const bool has_next_clip = clip + int(gridDim.x) < n_clips;
-        const float* __restrict__ x_next = has_next_clip ? x + int64_t(gridDim.x) * clip_stride : x;
+        const __amdgpu_buffer_rsrc_t rs_cur = clip_rsrc(clip), rs_next = clip_rsrc(clip + int(gridDim.x));
         float peak = 0.f;
-        // (sn, okmask) were prefetched: by the prologue for the first clip, by the previous clip's last frame otherwise
+        // `sn` was prefetched: by the prologue for the first clip, by the previous clip's last frame otherwise
 
 #pragma unroll 1
         for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
@@ -256,7 +242,7 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             float2 za[8], zb[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
-                const float4 s = (okmask >> n1) & 1u ? sn[n1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 s = sn[n1];
                 const float4 w = win4[64 * n1 + lane];
                 peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
                 za[n1] = make_float2(s.x * w.x, s.y * w.y);
@@ -325,11 +311,9 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             // next frame's samples: issued here, after the register-hungry FFT passes, and in flight under the
             // power / mel stages (about a third of the frame time, several times the HBM latency)
             {
-                const bool last = round + 1 == kFrames / kWavesPerBlock;            // uniform: data select, no branch
-                const float* __restrict__ xs = last ? x_next : x;
-                const int bs = last ? wave * kHop - kNfft / 2 + 4 * lane : base_next;
-                const unsigned m = load_frame<ALIGNED>(sn, xs, bs, clip_len, ring, ring_pos, ring_len);
-                okmask = (last && !has_next_clip) ? 0u : m;
+                const bool last = round + 1 == kFrames / kWavesPerBlock;            // uniform: descriptor select, no branch
+                load_frame<RING>(sn, last ? rs_next : rs_cur, last ? wave * kHop - kNfft / 2 + 4 * lane : base_next, ring_pos,
+                                 ring_len);
             }
             // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
             {
@@ -461,7 +445,7 @@ int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_
         WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
         lds_attr_set = true;
     }
-    if ((clip_len & 3) == 0)   // 16000-sample clips and the streaming ring: branch-free frame loads
+    if (ring_pos)
         hipLaunchKernelGGL(logmel_kernel<true>, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
                            int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
     else
