@@ -244,7 +244,8 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             for (int n1 = 0; n1 < 8; ++n1) {
                 const float4 s = sn[n1];
                 const float4 w = win4[64 * n1 + lane];
-                peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
+                // every sample sits in 4 frames; samples [512 t, 512 t + 512) = loads n1 4 and 5 of frame t tile the clip once
+                if (n1 == 4 || n1 == 5) peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
                 za[n1] = make_float2(s.x * w.x, s.y * w.y);
                 zb[n1] = make_float2(s.z * w.z, s.w * w.w);
             }
@@ -263,16 +264,24 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             STAMP(0);
             // ---- pass 2: lane = (k1, j): radix 8 over n2 of y[k1][16 n2 + 2j + q]; twiddle W_128; store X2 ----
             {
-                const int sw1 = 8 * ((k1r >> 1) & 1);
+                // (n2*8 + j) ^ 8s = (n2 ^ s)*8 + j: even n2 read from base + 8s, odd n2 from base - 8s, at immediate n2*8
+                const int s8 = 8 * ((k1r >> 1) & 1);
+                const float4* x1e = slab4 + k1r * 64 + jr + s8;
+                const float4* x1o = slab4 + k1r * 64 + jr - s8;
 #pragma unroll
                 for (int n2 = 0; n2 < 8; ++n2) {
-                    const float4 v = slab4[k1r * 64 + ((n2 * 8 + jr) ^ sw1)];
+                    const float4 v = (n2 & 1) ? x1o[n2 * 8] : x1e[n2 * 8];
                     za[n2] = make_float2(v.x, v.y);
                     zb[n2] = make_float2(v.z, v.w);
                 }
                 lds_order();
                 dft8(za);
                 dft8(zb);
+                // writer (k1, j), reader lane 8 k1 + k2, slot j ^ ((reader >> 1) & 7) = j ^ (4 (k1 & 1) + (k2 >> 1)):
+                // four lane bases (one per k2 >> 1), everything else is an immediate offset
+                float4* x2w[4];
+#pragma unroll
+                for (int hk = 0; hk < 4; ++hk) x2w[hk] = slab4 + 64 * k1r + (jr ^ (4 * (k1r & 1) + hk));
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
                     float2 a = za[k2], b = zb[k2];
@@ -281,8 +290,7 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
                         a = cmul(a, make_float2(t.x, t.y));
                         b = cmul(b, make_float2(t.z, t.w));
                     }
-                    const int reader = 8 * k1r + k2;
-                    slab4[reader * 8 + (jr ^ ((reader >> 1) & 7))] = make_float4(a.x, a.y, b.x, b.y);
+                    x2w[k2 >> 1][8 * k2] = make_float4(a.x, a.y, b.x, b.y);
                 }
             }
             lds_order();
@@ -300,11 +308,9 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
                 lds_order();
                 dft16(u);
                 const int lp = (lane >> 3) + 8 * (lane & 7);
+                float2* zw = slab2 + (lp ^ (((lp >> 4) & 3) << 1));     // bits 4-5 of k = lp + 64 kk are lp's: one base
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int k = lp + 64 * kk;
-                    slab2[k ^ (((k >> 4) & 3) << 1)] = u[kk];
-                }
+                for (int kk = 0; kk < 16; ++kk) zw[64 * kk] = u[kk];
             }
             lds_order();
             STAMP(2);
@@ -318,13 +324,18 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
             {
                 float2 a[8], b[8];
+                // k = lane + 64 j and 1024 - k = (64 - lane) + 64 (15 - j): the swizzle only involves the low 6 bits, so
+                // both streams are one lane base plus immediates (lane 0 pairs bin 512 with itself at j = 0, and its other
+                // partners 1024 - 64 j sit at 64 (16 - j) with a zero swizzle)
+                const int lowb = (64 - lane) & 63;
+                const float2* za_p = slab2 + (lane ^ (((lane >> 4) & 3) << 1));
+                const float2* zb_p = slab2 + (lowb ^ (((lowb >> 4) & 3) << 1)) + (lane == 0 ? 64 : 0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int k = (j == 0 && lane == 0) ? 512 : lane + 64 * j;
-                    const int kb = 1024 - k;
-                    a[j] = slab2[k ^ (((k >> 4) & 3) << 1)];
-                    b[j] = slab2[kb ^ (((kb >> 4) & 3) << 1)];
+                    a[j] = za_p[64 * j];
+                    b[j] = zb_p[64 * (15 - j)];
                 }
+                if (lane == 0) { a[0] = slab2[512]; b[0] = a[0]; }
                 lds_order();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
