@@ -223,7 +223,7 @@ def main():
                            "cnn2_kernel<POOL> (conv1 + conv2 + ReLU + avg-pool, v_mfma_f32_32x32x2_f32)") if args.arch == "simple"
                           else "cnn2 + cnn3 kernels (conv stack)",
                 "bound": "mfma", "achieved": k2_ach / 1e12, "peak": k2_peak / 1e12, "unit": "TFLOP/s",
-                "frac": k2_ach / k2_peak, "traffic": pmc_traffic("cnn2", B, args.arch),
+                "frac": k2_ach / k2_peak, "traffic": pmc_traffic("cnn2h16_kernel" if split else "cnn2_kernel", B, args.arch),
                 "flops_per_launch": k2_flops, "avg_launch_ms": k2_ms,
                 "note": ("achieved = ALGORITHMIC fp32 flops; the kernel issues 3 f16 MFMA flops per algorithmic flop, so the "
                          "matrix pipe runs at 3x this rate (ceiling for algorithmic flops = peak/3 = 833 TFLOP/s)") if split else
