@@ -138,8 +138,12 @@ def main():
     pooled = torch.empty((B, ops.c_last(n_conv)), device=dev)
     scratch_bytes = nat.check(nat.lib.ww_cnn_scratch_bytes(B, n_conv))
     scratch = torch.empty(max(1, scratch_bytes), device=dev, dtype=torch.uint8)
-    logits = torch.empty((B, 2), device=dev)
-    gathered = torch.empty((world * B, 2), device=dev) if world > 1 else logits
+    # logits / gathered are double-buffered: the all-gather of step k runs on RCCL's stream while step k+1 computes
+    logits2 = [torch.empty((B, 2), device=dev) for _ in range(2)]
+    gathered2 = [torch.empty((world * B, 2), device=dev) for _ in range(2)] if world > 1 else logits2
+    logits, gathered = logits2[0], gathered2[0]
+    pending = [None, None]
+    step_no = [0]
 
     import ctypes as C
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
@@ -147,6 +151,12 @@ def main():
     st = C.c_void_p(stream.cuda_stream)
 
     def step(ev=None):
+        b = step_no[0] & 1
+        step_no[0] += 1
+        logits, gathered = logits2[b], gathered2[b]
+        if pending[b] is not None:          # the gather that last used this buffer pair (two steps ago) must be done
+            pending[b].wait()
+            pending[b] = None
         if ev: ev[0].record(stream)
         nat.check(nat.lib.ww_logmel_f32(p(pcm), B, 16000, 16000, 1, p(mel), st))
         if ev: ev[1].record(stream)
@@ -160,9 +170,13 @@ def main():
                 dist.all_gather(parts, logits.cpu())
                 gathered.copy_(torch.cat(parts))
             else:
-                dist.all_gather_into_tensor(gathered, logits)
+                pending[b] = dist.all_gather_into_tensor(gathered, logits, async_op=True)
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -11,7 +11,7 @@
 //   f16x3 (default)  cnn2h16_kernel<POOL> [+ cnn3h_kernel]: every fp32 operand as two f16 halves, three
 //                    v_mfma_f32_16x16x32_f16 per product block, fp32 accumulate (~2^-21 relative).  12-wave workgroup:
 //                    8 consumer waves (2 per SIMD) + 4 producer waves that run conv1 -- itself an MFMA -- one band ahead
-//                    into a double-buffered LDS tile.  (cnn2h_kernel: the earlier 8-wave 32x32x16 form, WW_CNN_STRUCT=spec.)
+//                    into a double-buffered LDS tile.
 //   f32              cnn2_kernel<POOL> [+ cnn3_kernel]: v_mfma_f32_32x32x2_f32, exact fp32 (bit-for-bit an fmaf chain);
 //                    conv1 on the VALU per band.
 //
@@ -193,248 +193,23 @@ __global__ __launch_bounds__(256, 2) void cnn2_kernel(const float* __restrict__ 
 // conv1 + conv2 + pool with SPLIT-PRECISION conv2: every fp32 operand is carried as two f16 halves
 // (x ~= hi + lo, 22 significant bits) and each product block runs as three f16 MFMAs accumulating in fp32:
 //     a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi          (the dropped a_lo*w_lo is < 2^-22 relative)
-// v_mfma_f32_32x32x16_f16 does 16x the flops per cycle of v_mfma_f32_32x32x2_f32, so the matrix pipe needs
-// 3/16 of the cycles of the exact-f32 kernel.  f16 products (11 x 11 bits) are exact in the fp32 accumulator.
-// Weights are pre-scaled by 2^S on the host (both halves normal f16); the accumulator is descaled by 2^-S.
-//
-// LDS tile: channels-last, one 144-byte record per image position:  [32 ci hi f16][32 ci lo f16][16 B pad]
-// (the pad makes consecutive positions 36 dwords apart: ds_read_b128 / ds_write_b128 conflict-free).
-// k-step = (channel block cb of 16, dx, dy): lane (x, h) reads the 8 channels 16cb+8h.. of position (q, x+dx)
-// with ONE ds_read_b128 per half; an input row's fragments serve every (output row, dy) pair that touches it.
+// Split precision: the f16 matrix instructions do 16x the flops per cycle of v_mfma_f32_32x32x2_f32, so three of them
+// per product block need 3/16 of the exact-f32 kernel's matrix-pipe cycles.  f16 products (11 x 11 bits) are exact in
+// the fp32 accumulator.  Weights are pre-scaled by 2^S on the host (both halves normal f16); the accumulator is
+// descaled by 2^-S.
 // ------------------------------------------------------------------------------------------------
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
-constexpr int kPosBytes = 144;                               // one position record
-constexpr int kHRowBytes = kRS * kPosBytes;                  // 34 positions per tile row
-constexpr int kHActBytes = kARows * kHRowBytes;              // 48,960
-
-__device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b) {
-    return uint32_t(__builtin_bit_cast(uint16_t, a)) | (uint32_t(__builtin_bit_cast(uint16_t, b)) << 16);
-}
-
-// conv1 for one band straight into the split f16 tile.  wave w computes channels 8w..8w+7 of (row q, column x)
-// and stores them as one 16-byte hi block and one 16-byte lo block.
-__device__ __forceinline__ void conv1_band_split(const float* __restrict__ melt, char* __restrict__ act,
-                                                 const float* __restrict__ w1, const float* __restrict__ b1, int y0,
-                                                 int width, int wave, int lane) {
-    const int x = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int i = 0; i < kARows / 2; ++i) {
-        const int q = 2 * i + h;
-        const int y = y0 - 1 + q;
-        const bool inside = (y >= 0) && (y < kH) && (x < width);
-        const float* m = melt + (inside ? y : 0) * kMelRS + x;
-        const float m00 = m[0], m01 = m[1], m02 = m[2];
-        const float m10 = m[kMelRS], m11 = m[kMelRS + 1], m12 = m[kMelRS + 2];
-        const float m20 = m[2 * kMelRS], m21 = m[2 * kMelRS + 1], m22 = m[2 * kMelRS + 2];
-        _Float16 hi[8], lo[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int ci = 8 * wave + u;
-            const float* w = w1 + ci * 9;
-            float v = b1[ci];
-            v = fmaf(w[0], m00, v); v = fmaf(w[1], m01, v); v = fmaf(w[2], m02, v);
-            v = fmaf(w[3], m10, v); v = fmaf(w[4], m11, v); v = fmaf(w[5], m12, v);
-            v = fmaf(w[6], m20, v); v = fmaf(w[7], m21, v); v = fmaf(w[8], m22, v);
-            v = inside ? relu(v) : 0.f;
-            hi[u] = static_cast<_Float16>(v);
-            lo[u] = static_cast<_Float16>(v - static_cast<float>(hi[u]));
-        }
-        char* rec = act + (q * kRS + x + 1) * kPosBytes + wave * 16;
-        u32x4 vh, vl;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { vh[d] = pack_h2(hi[2 * d], hi[2 * d + 1]); vl[d] = pack_h2(lo[2 * d], lo[2 * d + 1]); }
-        *reinterpret_cast<u32x4*>(rec) = vh;
-        *reinterpret_cast<u32x4*>(rec + 64) = vl;
-    }
-}
-
-// Shared MFMA body of the split-precision kernels: 36 fragment steps it = (cb*3 + dx)*6 + q over 4 output rows,
-// software-pipelined one step ahead (ds_read_b128 of step it+1 is in flight under the MFMAs of step it).
-__device__ __forceinline__ void mfma_rows4_f16x3(const char* __restrict__ ap, const half8 (&bh)[18], const half8 (&bl)[18],
-                                                 f32x16 (&acc)[4]) {
-    auto frag = [&](int it, int half) -> half8 {
-        const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
-        return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + dx) * kPosBytes + cb * 32 + half * 64));
-    };
-    half8 ah = frag(0, 0), al = frag(0, 1);
-#pragma unroll
-    for (int it = 0; it < 36; ++it) {
-        half8 ahn = ah, aln = al;
-        if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
-        const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int r = q - dy;
-            if (r < 0 || r > 3) continue;
-            const int ks = (cb * 3 + dx) * 3 + dy;
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[r], 0, 0, 0);
-        }
-        ah = ahn; al = aln;
-    }
-}
-
 // 2*relu(v) = v + |v| : one VALU op, exact, NaN-propagating (the factor 2 is folded into the pool scale)
 __device__ __forceinline__ float relu2(float v) { return v + __builtin_fabsf(v); }
 
-// Workgroup = 8 waves with fixed roles, one workgroup per CU (persistent over clips):
-//   waves 0-3  CONSUMERS: (row group, N-tile) MFMA tiles of the current band + bias/ReLU/pool epilogue
-//   waves 4-7  PRODUCERS: conv1 of the NEXT band on the VALU into the other half of a double-buffered LDS tile,
-//              and the next clip's log-mel image into a double-buffered mel tile
-// so each SIMD hosts one matrix-pipe wave and one VALU wave that overlap in hardware; one barrier per band.
-constexpr int kC2hLdsBytes2 = 2 * kHActBytes + 2 * kMelFloats * 4 + 4 * 32 * 4;
-
-template <bool POOL>
-__global__ __launch_bounds__(512, 2) void cnn2h_kernel(const float* __restrict__ mel, int n, int width,
-                                                       const float* __restrict__ w1, const float* __restrict__ b1,
-                                                       const u32x4* __restrict__ wH, const float* __restrict__ hs,
-                                                       const float* __restrict__ b2, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    char* act0 = ldsb;                                                       // 2 x [10][34] records of 144 B
-    float* melt0 = reinterpret_cast<float*>(ldsb + 2 * kHActBytes);          // 2 x [82][36]
-    float* red = melt0 + 2 * kMelFloats;                                     // [4][32]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wave < 4;
-    const int nt = wave & 1, rg = (wave >> 1) & 1;
-    const int x = lane & 31, h = lane >> 5;
-    const int ptid = tid - 256;                                              // producer thread index 0..255
-
-    half8 bh[18], bl[18];
-    float bias = 0.f, descale = 0.f;
-    if (consumer) {
-#pragma unroll
-        for (int ks = 0; ks < 18; ++ks) {
-            bh[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 0) * 64 + lane]);
-            bl[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 1) * 64 + lane]);
-        }
-        bias = b2[32 * nt + x];
-        descale = hs[0];
-    }
-    for (int i = tid; i < kC2hLdsBytes2 / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
-    __syncthreads();
-
-    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);   // clips blockIdx.x + i*gridDim.x
-    const int steps = my_clips * (kH / kBand);
-    const float inv_area = 1.0f / float(kH * width);
-
-    auto load_mel = [&](int k) {     // producers: log-mel image of this workgroup's k-th clip -> melt[k & 1]
-        const float* __restrict__ src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kH * width;
-        float* mt = melt0 + (k & 1) * kMelFloats;
-        for (int i = ptid; i < kH * width; i += 256) {
-            const int y = i / width, xx = i - y * width;
-            mt[(y + 1) * kMelRS + xx + 1] = src[i];
-        }
-    };
-    auto produce = [&](int g) {      // producers: conv1 of step g (clip g/10, band g%10) -> act[g & 1]
-        const int k = g / (kH / kBand), band = g - k * (kH / kBand);
-        conv1_band_split(melt0 + (k & 1) * kMelFloats, act0 + (g & 1) * kHActBytes, w1, b1, band * kBand, width,
-                         wave - 4, lane);
-    };
-
-    if (!consumer && steps > 0) load_mel(0);
-    __syncthreads();
-    if (!consumer && steps > 0) {
-        produce(0);
-        if (my_clips > 1) load_mel(1);
-    }
-    __syncthreads();
-
-    float pool = 0.f;
-    for (int g = 0; g < steps; ++g) {
-        const int k = g / (kH / kBand), band = g - k * (kH / kBand);
-        if (consumer) {
-            if constexpr (POOL) {
-                if (band == 0 && g > 0 && wave == 0) {      // previous clip's pooled sums are complete in `red`
-                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k - 1) * gridDim.x;
-                    out[clip * 64 + lane] = (red[(lane >> 5) * 32 + (lane & 31)] + red[(2 + (lane >> 5)) * 32 + (lane & 31)]) * inv_area;
-                }
-            }
-            const char* ap = act0 + (g & 1) * kHActBytes + ((rg * 4) * kRS + x) * kPosBytes + h * 16;
-            f32x16 acc[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
-            // 36 fragment steps it = (cb*3 + dx)*6 + q, software-pipelined one step ahead: with a single matrix-pipe
-            // wave per SIMD nothing else hides the ds_read_b128 latency.
-            auto frag = [&](int it, int half) -> half8 {
-                const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
-                return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + dx) * kPosBytes + cb * 32 + half * 64));
-            };
-            half8 ah = frag(0, 0), al = frag(0, 1);
-#pragma unroll
-            for (int it = 0; it < 36; ++it) {
-                half8 ahn = ah, aln = al;
-                if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
-                const int cb = it / 18, dx = (it / 6) % 3, q = it % 6;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int r = q - dy;
-                    if (r < 0 || r > 3) continue;
-                    const int ks = (cb * 3 + dx) * 3 + dy;
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc[r], 0, 0, 0);
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc[r], 0, 0, 0);
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc[r], 0, 0, 0);
-                }
-                ah = ahn; al = aln;
-            }
-            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-            if constexpr (POOL) {
-                if (band == 0) pool = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
-                        const float v = relu(fmaf(acc[r][j], descale, bias));
-                        pool += (col < width) ? v : 0.f;
-                    }
-                if (band == kH / kBand - 1) {
-                    const float p2 = pool + __shfl_xor(pool, 32);
-                    if (lane < 32) red[wave * 32 + lane] = p2;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = band * kBand + rg * 4 + r;
-                    float* dst = out + ((clip * kH + y) * 64 + 32 * nt + x) * kW;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int col0 = 8 * gq + 4 * h;
-                        float4 v;
-                        v.x = (col0 + 0 < width) ? relu(fmaf(acc[r][4 * gq + 0], descale, bias)) : 0.f;
-                        v.y = (col0 + 1 < width) ? relu(fmaf(acc[r][4 * gq + 1], descale, bias)) : 0.f;
-                        v.z = (col0 + 2 < width) ? relu(fmaf(acc[r][4 * gq + 2], descale, bias)) : 0.f;
-                        v.w = (col0 + 3 < width) ? relu(fmaf(acc[r][4 * gq + 3], descale, bias)) : 0.f;
-                        *reinterpret_cast<float4*>(dst + col0) = v;
-                    }
-                }
-            }
-        } else if (g + 1 < steps) {
-            produce(g + 1);
-            const int k1 = (g + 1) / (kH / kBand);
-            if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);   // two clips ahead of the MFMAs
-        }
-        __syncthreads();
-    }
-    if constexpr (POOL) {
-        if (consumer && wave == 0 && steps > 0) {
-            const int64_t clip = int64_t(blockIdx.x) + int64_t(my_clips - 1) * gridDim.x;
-            out[clip * 64 + lane] = (red[(lane >> 5) * 32 + (lane & 31)] + red[(2 + (lane >> 5)) * 32 + (lane & 31)]) * inv_area;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// 16x16x32 variant of the split-precision kernel: 12 waves per workgroup (one per CU, 3 waves per SIMD, <= 168 VGPRs):
+// Split-precision conv1+conv2 kernel (v_mfma_f32_16x16x32_f16): 12 waves per workgroup (one per CU, 3 waves per SIMD,
+// <= 168 VGPRs):
 //   waves 0-7   CONSUMERS = (row group of 4 rows) x (N-tile of 16 channels): 72 B-operand VGPRs each, so TWO matrix-pipe
 //               waves share every SIMD and hide each other's LDS latency (one 250-VGPR wave per SIMD cannot)
-//   waves 8-11  PRODUCERS: conv1 of the next band (VALU) into the other half of the double-buffered tile
+//   waves 8-11  PRODUCERS: conv1 of the next band (itself an MFMA) into the other half of the double-buffered tile
 // Position record = 160 bytes ([32 ci hi][32 ci lo][32 B pad]): conflict-free for the 16x16x32 A-fragment reads
 // (lane = (position i, channel quarter kq) reads 16 B at position*160 + kq*16).
 // ------------------------------------------------------------------------------------------------
@@ -443,41 +218,6 @@ constexpr int kPos16 = 160;
 constexpr int kH16Row = kRS * kPos16;
 constexpr int kH16Act = kARows * kH16Row;                   // 54,400 B per buffer
 constexpr int kC2h16Lds = 2 * kH16Act + 4 * ((kH + 2) * 36) * 2 + 8 * 16 * 4;
-
-__device__ __forceinline__ void conv1_band_split16(const float* __restrict__ melt, char* __restrict__ act,
-                                                   const float* __restrict__ w1, const float* __restrict__ b1, int y0,
-                                                   int width, int pw, int lane) {
-    const int x = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int i = 0; i < kARows / 2; ++i) {
-        const int q = 2 * i + h;
-        const int y = y0 - 1 + q;
-        const bool inside = (y >= 0) && (y < kH) && (x < width);
-        const float* m = melt + (inside ? y : 0) * kMelRS + x;
-        const float m00 = m[0], m01 = m[1], m02 = m[2];
-        const float m10 = m[kMelRS], m11 = m[kMelRS + 1], m12 = m[kMelRS + 2];
-        const float m20 = m[2 * kMelRS], m21 = m[2 * kMelRS + 1], m22 = m[2 * kMelRS + 2];
-        _Float16 hi[8], lo[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int ci = 8 * pw + u;
-            const float* w = w1 + ci * 9;
-            float v = b1[ci];
-            v = fmaf(w[0], m00, v); v = fmaf(w[1], m01, v); v = fmaf(w[2], m02, v);
-            v = fmaf(w[3], m10, v); v = fmaf(w[4], m11, v); v = fmaf(w[5], m12, v);
-            v = fmaf(w[6], m20, v); v = fmaf(w[7], m21, v); v = fmaf(w[8], m22, v);
-            v = inside ? relu(v) : 0.f;
-            hi[u] = static_cast<_Float16>(v);
-            lo[u] = static_cast<_Float16>(v - static_cast<float>(hi[u]));
-        }
-        char* rec = act + (q * kRS + x + 1) * kPos16 + pw * 16;
-        u32x4 vh, vl;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { vh[d] = pack_h2(hi[2 * d], hi[2 * d + 1]); vl[d] = pack_h2(lo[2 * d], lo[2 * d + 1]); }
-        *reinterpret_cast<u32x4*>(rec) = vh;
-        *reinterpret_cast<u32x4*>(rec + 64) = vl;
-    }
-}
 
 // conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
 //   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
@@ -974,84 +714,64 @@ int64_t cnn_scratch_bytes(int64_t n, int n_conv) {
     return n_conv == 3 ? n * int64_t(kH) * 64 * kW * int64_t(sizeof(float)) : 0;
 }
 
+// > 64 KiB of dynamic LDS needs an opt-in per kernel, once per device
+static int opt_in_lds() {
+    static bool done[64] = {};
+    int dev = 0;
+    WW_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
+    if (done[dev]) return WW_OK;
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(sizeof(float) * kC3LdsFloats)));
+    done[dev] = true;
+    return WW_OK;
+}
+
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
                     float* pooled, hipStream_t stream) {
     if (n == 0) return WW_OK;
+    if (n_conv == 3 && !scratch) return fail(WW_EINVAL, "n_conv == 3 needs ww_cnn_scratch_bytes() of scratch");
     const PackedLayout L = packed_layout(n_conv);
-    const int64_t resident = int64_t(device_cu_count()) * 2;
-    const int grid = int(n < resident ? n : resident);
-    const size_t lds2 = sizeof(float) * kC2LdsFloats;
-    const bool split = conv_math_mode() == 1;
-    const int grid_h = int(n < device_cu_count() ? n : device_cu_count());     // one 8-wave workgroup per CU
-    static bool h_attr_set = false;     // > 64 KiB of dynamic LDS needs the opt-in once per process
-    if (split && !h_attr_set) {
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2hLdsBytes2));
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2hLdsBytes2));
-        h_attr_set = true;
-    }
-    const u32x4* wH = reinterpret_cast<const u32x4*>(packed + L.conv2_h);
-    // WW_CNN_STRUCT (tuning knob): "n16" (default) 12-wave 16x16x32 kernel; "spec" 8-wave 32x32x16 kernel
-    static const int h_struct = [] {
-        const char* e = getenv("WW_CNN_STRUCT");
-        return (e && e[0] == 's') ? 1 : 2;
-    }();
-    if (split && h_struct == 2) {
-        static bool a16 = false;
-        if (!a16) {
-            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
-            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
-            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
-            a16 = true;
-        }
+    if (int rc = opt_in_lds()) return rc;
+    const int cus = device_cu_count();
+    const int grid1 = int(n < cus ? n : cus);                  // persistent: one workgroup per CU
+    if (conv_math_mode() == 1) {                               // f16x3
+        const u32x4* w1h = reinterpret_cast<const u32x4*>(packed + L.conv1_h);
+        const u32x4* w2h = reinterpret_cast<const u32x4*>(packed + L.conv2_h16);
         if (n_conv == 2) {
-            hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid_h), dim3(768), kC2h16Lds, stream, mel, int(n), width,
-                               packed + L.conv1_w, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv1_h),
-                               reinterpret_cast<const u32x4*>(packed + L.conv2_h16),
-                               packed + L.conv2_hs, packed + L.conv2_b, pooled);
+            hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width,
+                               packed + L.conv1_w, packed + L.conv1_b, w1h, w2h, packed + L.conv2_hs, packed + L.conv2_b,
+                               pooled);
             WW_HIP(hipGetLastError());
             return WW_OK;
         }
-        if (!scratch) return fail(WW_EINVAL, "n_conv == 3 needs ww_cnn_scratch_bytes() of scratch");
-        hipLaunchKernelGGL(cnn2h16_kernel<false>, dim3(grid_h), dim3(768), kC2h16Lds, stream, mel, int(n), width,
-                           packed + L.conv1_w, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv1_h),
-                           reinterpret_cast<const u32x4*>(packed + L.conv2_h16),
-                           packed + L.conv2_hs, packed + L.conv2_b, static_cast<float*>(scratch));
+        hipLaunchKernelGGL(cnn2h16_kernel<false>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width,
+                           packed + L.conv1_w, packed + L.conv1_b, w1h, w2h, packed + L.conv2_hs, packed + L.conv2_b,
+                           static_cast<float*>(scratch));
         WW_HIP(hipGetLastError());
-        hipLaunchKernelGGL(cnn3h_kernel, dim3(grid_h), dim3(512), kC3hLds, stream, static_cast<const _Float16*>(scratch), int(n),
-                           width, reinterpret_cast<const u32x4*>(packed + L.conv3_h), packed + L.conv3_hs, packed + L.conv3_b,
-                           pooled);
+        hipLaunchKernelGGL(cnn3h_kernel, dim3(grid1), dim3(512), kC3hLds, stream, static_cast<const _Float16*>(scratch),
+                           int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_h), packed + L.conv3_hs,
+                           packed + L.conv3_b, pooled);
         WW_HIP(hipGetLastError());
         return WW_OK;
     }
-    if (n_conv == 2 && split) {
-        hipLaunchKernelGGL(cnn2h_kernel<true>, dim3(grid_h), dim3(512), kC2hLdsBytes2, stream, mel, int(n), width,
-                           packed + L.conv1_w, packed + L.conv1_b, wH, packed + L.conv2_hs, packed + L.conv2_b, pooled);
-        WW_HIP(hipGetLastError());
-        return WW_OK;
-    }
+    // exact f32
+    const int grid2 = int(n < 2 * int64_t(cus) ? n : 2 * int64_t(cus));   // two 4-wave workgroups per CU
+    const size_t lds2 = sizeof(float) * kC2LdsFloats;
     if (n_conv == 2) {
-        hipLaunchKernelGGL(cnn2_kernel<true>, dim3(grid), dim3(256), lds2, stream, mel, int(n), width,
+        hipLaunchKernelGGL(cnn2_kernel<true>, dim3(grid2), dim3(256), lds2, stream, mel, int(n), width,
                            packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, pooled);
         WW_HIP(hipGetLastError());
         return WW_OK;
     }
-    if (!scratch) return fail(WW_EINVAL, "n_conv == 3 needs ww_cnn_scratch_bytes() of scratch");
     float* mid = static_cast<float*>(scratch);
-    if (split)
-        hipLaunchKernelGGL(cnn2h_kernel<false>, dim3(grid_h), dim3(512), kC2hLdsBytes2, stream, mel, int(n), width,
-                           packed + L.conv1_w, packed + L.conv1_b, wH, packed + L.conv2_hs, packed + L.conv2_b, mid);
-    else
-        hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid), dim3(256), lds2, stream, mel, int(n), width,
-                           packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, mid);
+    hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid2), dim3(256), lds2, stream, mel, int(n), width,
+                       packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, mid);
     WW_HIP(hipGetLastError());
-    const int grid3 = int(n < device_cu_count() ? n : device_cu_count());
-    static bool lds_attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
-    if (!lds_attr_set) {
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   int(sizeof(float) * kC3LdsFloats)));
-        lds_attr_set = true;
-    }
-    hipLaunchKernelGGL(cnn3_kernel, dim3(grid3), dim3(512), sizeof(float) * kC3LdsFloats, stream, mid, int(n), width,
+    hipLaunchKernelGGL(cnn3_kernel, dim3(grid1), dim3(512), sizeof(float) * kC3LdsFloats, stream, mid, int(n), width,
                        packed + L.conv3_w, packed + L.conv3_b, pooled);
     WW_HIP(hipGetLastError());
     return WW_OK;

@@ -76,8 +76,7 @@ struct PackedLayout {
     int64_t l1_b;      // [768]
     int64_t fc_w;      // [2][256]
     int64_t fc_b;      // [2] (+2 pad)
-    // split-precision image of conv2 for the f16x3 kernel: W * 2^S = hi + lo (two f16), MFMA 32x32x16 B-operand order
-    int64_t conv2_h;   // [2 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64 lanes][4 dwords = 8 f16]
+    // split-precision images for the f16x3 kernels: W * 2^S = hi + lo (two f16) in MFMA operand order
     int64_t conv2_hs;  // [4]: 2^-S (descale applied to the f32 accumulator), S, 0, 0
     int64_t conv1_h;   // conv1 as a 32x32x16 f16 MFMA A operand: [hi,lo][64 lanes][4 dwords]; k = tap 0..8, k = 9: bias
     int64_t conv3_h;   // (n_conv 3) conv3 split-precision B operands for 16x16x32: [8 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64][4]

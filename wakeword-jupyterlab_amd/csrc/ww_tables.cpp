@@ -135,7 +135,6 @@ PackedLayout packed_layout(int n_conv) {
     L.l1_b = take(kGateCols);
     L.fc_w = take(2 * kHidden);
     L.fc_b = take(4);
-    L.conv2_h = take(2 * 18 * 2 * 64 * 4);
     L.conv2_hs = take(4);
     L.conv3_h = n_conv == 3 ? take(8 * 18 * 2 * 64 * 4) : -1;
     L.conv3_hs = n_conv == 3 ? take(4) : -1;
@@ -159,11 +158,11 @@ static void pack_conv_b_operand(const float* w, int cout, int cin, float* out) {
                     }
 }
 
-// conv2 weight [64][32][3][3] -> split-precision f16 B operands for v_mfma_f32_32x32x16_f16.
+// conv2 weight [64][32][3][3] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16.
 // W' = W * 2^S (S chosen so that max|W'| lies in [2^12, 2^13): both halves stay normal f16), W' ~= hi + lo.
-// k-step ks = (cb*3 + dx)*3 + dy covers input channels 16*cb .. 16*cb+15 of tap (dy, dx); lane (n = lane&31,
-// h = lane>>5) holds B[k = 8h + j][n] = W'[32*nt + n][16*cb + 8h + j][dy][dx], j = 0..7, as 4 dwords.
-static float pack_conv2_f16x3(const float* w, float* out_words, float* out_words16) {
+// k-step ks = dx*3 + dy covers all 32 input channels of tap (dy, dx); lane (n = lane&15, kq = lane>>4) holds
+// B[k = 8kq + j][n] = W'[16*nt + n][8kq + j][dy][dx], j = 0..7, as 4 dwords.  Returns the descale 2^-S.
+static float pack_conv2_f16x3(const float* w, float* out_words16) {
     float wmax = 0.f;
     for (int i = 0; i < 64 * 32 * 9; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
     int S = 0;
@@ -171,28 +170,6 @@ static float pack_conv2_f16x3(const float* w, float* out_words, float* out_words
     if (S > 24) S = 24;
     if (S < -8) S = -8;
     const float scale = std::ldexp(1.0f, S);
-    uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
-    for (int nt = 0; nt < 2; ++nt)
-        for (int cb = 0; cb < 2; ++cb)
-            for (int dx = 0; dx < 3; ++dx)
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int ks = (cb * 3 + dx) * 3 + dy;
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int co = 32 * nt + (lane & 31), ci = 16 * cb + 8 * (lane >> 5) + j;
-                            const float v = w[((co * 32 + ci) * 3 + dy) * 3 + dx] * scale;
-                            const _Float16 hi = static_cast<_Float16>(v);
-                            const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
-                            uint16_t hb, lb;
-                            std::memcpy(&hb, &hi, 2);
-                            std::memcpy(&lb, &lo, 2);
-                            const int64_t base = ((int64_t(nt) * 18 + ks) * 2) * 64 * 8;   // in f16 units
-                            o16[base + lane * 8 + j] = hb;
-                            o16[base + 64 * 8 + lane * 8 + j] = lb;
-                        }
-                }
-    // second image, for the 16x16x32 tiles: k-step ks = dx*3 + dy covers all 32 input channels of a tap; lane
-    // (n = lane&15, kq = lane>>4) holds B[k = 8kq + j][n] = W'[16*nt + n][8kq + j][dy][dx], j = 0..7
     uint16_t* o16b = reinterpret_cast<uint16_t*>(out_words16);
     for (int nt = 0; nt < 4; ++nt)
         for (int dx = 0; dx < 3; ++dx)
@@ -343,7 +320,7 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     std::memcpy(out + L.fc_b, sd->fc_bias, sizeof(float) * 2);
     if (sd->n_conv == 3) out[L.conv3_hs] = pack_conv3_f16x3(sd->conv_weight[2], out + L.conv3_h);
     pack_conv1_f16x3(sd->conv_weight[0], sd->conv_bias[0], out + L.conv1_h);
-    out[L.conv2_hs] = pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h, out + L.conv2_h16);
+    out[L.conv2_hs] = pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h16);
     return WW_OK;
 }
 
