@@ -18,6 +18,8 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   cpu_baseline  the CPU oracle (numpy log-mel per clip + torch CPU Conv2d/LSTM/Linear) timed on this
                 host on a bounded sample of the same clips (rank 0, N = 1 only)
   parity        max |err| of the measured path against that oracle on the sample
+  streaming     BASELINE configs[4] (256 microphones, 10 ms hop, hipGraph replay per hop): p50/p99 hop latency, hops/s
+                (rank 0, N = 1 only; measured after the timed region)
 """
 import argparse
 import json
@@ -97,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU per step")
     ap.add_argument("--arch", default="simple", choices=["simple", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the streaming (256 mics, 10 ms hop) latency leg")
     ap.add_argument("--conv-math", default=None, choices=["f32", "f16x3"], help="conv2 arithmetic (default: library default)")
     args = ap.parse_args()
 
@@ -274,6 +277,11 @@ def main():
                              "logits_max_abs_err": float(np.abs(got_logits - ref_logits).max()),
                              "against": "oracle/ (librosa is not installed: mel parity vs librosa itself is unpinned)"}
             out["gpu_over_cpu"] = clips_per_s / base["value"]
+        if world == 1 and not args.no_streaming and args.arch == "simple":
+            # BASELINE configs[4]: 256 microphones, 10 ms hop, one hipGraph replay per hop (after the timed region)
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_streaming
+            out["streaming"] = bench_streaming.measure(mics=256, hop=160, hops=1000, device=dev.index)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

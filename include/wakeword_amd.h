@@ -114,6 +114,30 @@ WW_API int ww_resampler_prepare(int32_t sample_rate, ww_clip_desc* desc_host);
 WW_API int ww_decode_resample(const uint8_t* raw_dev, const ww_clip_desc* descs_dev, int64_t n_clips, int normalize,
                               float* pcm_out_dev, ww_stream_t stream);
 
+/* ---- KA: training-time augmentation ------------------------------ */
+/* Replaces AudioProcessor.augment_audio (wakeword_training_script.py:103-123): np.roll time shift ->
+ * librosa.effects.pitch_shift -> librosa.effects.time_stretch + pad_or_truncate -> additive Gaussian noise.
+ * The random draws stay with the caller (the reference uses Python's `random`): one plan per clip.
+ * librosa's phase vocoder (n_fft 2048, hop 512, Hann) is restated; its resampler (soxr_hq, third party)
+ * is replaced by a Kaiser-windowed-sinc interpolator (resampy 'kaiser_best' design) and np.random.normal by
+ * the build's counter-based generator: parity against librosa itself is unpinned (oracle/augment_oracle.py). */
+typedef struct ww_augment_plan {
+    int32_t shift;        /* np.roll shift in samples, any sign; 0 = no shift (:106-108) */
+    int32_t crop_start;   /* pad_or_truncate's random crop start after time_stretch, in [0, round(16000/rate) - 16000] */
+    double pitch_rate;    /* 2^(-n_steps/12) of pitch_shift (:110-112); 0 = off */
+    double stretch_rate;  /* time_stretch rate (:114-117); 0 = off.  Both rates: 32/46 <= rate < 32 */
+    float noise_sigma;    /* NOISE_FACTOR (:119-121); 0 = off */
+    uint32_t noise_seed;
+} ww_augment_plan;
+WW_API int64_t ww_augment_workspace_bytes(int64_t n_clips);
+/* pcm_dev [n_clips] rows of 16000 samples at pcm_dev + i*clip_stride (16-byte aligned, clip_stride % 4 == 0);
+ * plans_host [n_clips] in HOST memory (read before the call returns); out_dev [n_clips][16000], may alias pcm_dev;
+ * workspace_dev >= ww_augment_workspace_bytes(n_clips), 256-byte aligned. */
+WW_API int ww_augment_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, const ww_augment_plan* plans_host,
+                   float* out_dev, void* workspace_dev, ww_stream_t stream);
+/* The resampler's half-window (32769 floats: 64 zero crossings x 512 + 1) on the host, for checking on a CPU. */
+WW_API int ww_kaiser_best_host(float* out_host);
+
 /* ---- K1: log-mel front-end --------------------------------------------------------------- */
 /* Replaces AudioProcessor.normalize_audio (:73-76), the zero-pad branch of pad_or_truncate
  * (:78-83) and AudioProcessor.audio_to_mel (:85-101) =

@@ -23,9 +23,12 @@ def run(h):
         rc = h.ww_cnn_pool_f32(C.c_void_p(mel.data_ptr()), C.c_int64(B), 32, C.c_void_p(packed.data_ptr()), 2, None, C.c_void_p(pooled.data_ptr()), None)
     assert rc == 0, rc
 res = {p: [] for p in libs}
-for h in hs:
+for path, h in zip(libs, hs):
     for _ in range(3): run(h)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    if what == "logmel":      # every build must reproduce the shipped library's result
+        print("%-40s max |diff| vs shipped %.3g" % (path.split("/")[-1], float((out - mel.view_as(out)).abs().max())))
+        out.zero_()
 for rnd in range(12):
     for p, h in zip(libs, hs):
         torch.cuda.synchronize(); t = time.perf_counter()

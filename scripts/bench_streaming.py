@@ -17,13 +17,10 @@ import torch  # noqa: E402
 import wakeword_jupyterlab_amd as pkg  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--mics", type=int, default=256)
-    ap.add_argument("--hop", type=int, default=160)
-    ap.add_argument("--hops", type=int, default=1000)
-    args = ap.parse_args()
-    dev = torch.device("cuda", 0)
+def measure(mics=256, hop=160, hops=1000, device=0):
+    """Run the streaming config and return its result dict (bench.py embeds it in its JSON line at N=1)."""
+    args = argparse.Namespace(mics=mics, hop=hop, hops=hops)
+    dev = torch.device("cuda", device)
     sd = pkg.synth.make_state_dict("simple", seed=1234)
     m = pkg.SimpleWakewordModel()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -64,8 +61,17 @@ def main():
            "latency_us_max": float(lat.max() * 1e6), "hops_per_s_back_to_back": thr, "windows_per_s": thr * args.mics,
            "device_us_per_replay": dev_us, "realtime_factor": thr * args.hop / 16000.0,
            "finite_probs": int(torch.isfinite(det.prob).sum().item())}
-    print(json.dumps(out))
     det.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mics", type=int, default=256)
+    ap.add_argument("--hop", type=int, default=160)
+    ap.add_argument("--hops", type=int, default=1000)
+    args = ap.parse_args()
+    print(json.dumps(measure(args.mics, args.hop, args.hops)))
 
 
 if __name__ == "__main__":

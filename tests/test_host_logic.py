@@ -80,8 +80,8 @@ def test_unsupported_configurations_are_refused():
         HIDDEN_SIZE = 128
     with pytest.raises(NotImplementedError):
         pkg.WakewordModel(config=MC)
-    with pytest.raises(NotImplementedError):
-        AudioProcessor().augment_audio(np.zeros(16000))
+    with pytest.raises(ValueError):
+        AudioProcessor().augment_audio(np.zeros(100))               # exactly one padded clip, as process_audio_file passes it
 
 
 def test_wav_reader_and_load_audio(tmp_path):
@@ -132,8 +132,7 @@ def test_dataset_bookkeeping_and_load_clips(tmp_path, capsys):
     assert pcm.shape == (4, 16000) and list(ok) == [True, True, True, False]
     assert abs(np.abs(pcm[0]).max() - 1.0) < 1e-6 and not pcm[0, 9000:].any()      # peak-normalised, right zero-padded
     assert not pcm[3].any()
-    with pytest.raises(NotImplementedError):
-        WakewordDataset(files, [], AudioProcessor(), augment=True)
+    assert WakewordDataset(files, [], AudioProcessor(), augment=True, verbose=False).augment is True    # training split (:456)
 
 
 def test_synth_is_deterministic_and_follows_the_recipe():

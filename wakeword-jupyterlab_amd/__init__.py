@@ -19,7 +19,8 @@ def __getattr__(name):
         return importlib.import_module(f"{__name__}.{name}")
     lazy = {"AudioProcessor": "audio", "WakewordDataset": "dataset", "SimpleWakewordModel": "model",
             "WakewordModel": "model", "StreamingDetector": "streaming", "predict_wakeword": "inference",
-            "evaluate": "inference", "AudioConfig": "config", "ModelConfig": "config", "Config": "config"}
+            "evaluate": "inference", "AudioConfig": "config", "ModelConfig": "config", "Config": "config",
+            "AugmentationConfig": "config"}
     if name in lazy:
         return getattr(importlib.import_module(f"{__name__}.{lazy[name]}"), name)
     raise AttributeError(name)

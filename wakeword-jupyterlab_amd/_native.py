@@ -47,6 +47,14 @@ class ClipDesc(C.Structure):
     ]
 
 
+class AugmentPlan(C.Structure):
+    """struct ww_augment_plan (include/wakeword_amd.h)."""
+    _fields_ = [
+        ("shift", C.c_int32), ("crop_start", C.c_int32), ("pitch_rate", C.c_double), ("stretch_rate", C.c_double),
+        ("noise_sigma", C.c_float), ("noise_seed", C.c_uint32),
+    ]
+
+
 FMT_S16, FMT_S24, FMT_S32, FMT_F32, FMT_U8 = 1, 2, 3, 4, 5
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header
@@ -62,6 +70,9 @@ PROTOTYPES = {
     "ww_resample_taps_host": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ww_resampler_prepare": (C.c_int, [C.c_int32, C.POINTER(ClipDesc)]),
     "ww_decode_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "ww_augment_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "ww_augment_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(AugmentPlan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ww_kaiser_best_host": (C.c_int, [C.c_void_p]),
     "ww_logmel_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "ww_packed_weights_floats": (C.c_int64, [C.c_int32]),
     "ww_pack_weights_host": (C.c_int, [C.POINTER(StateDict), C.c_void_p]),

@@ -9,7 +9,8 @@ Same method names, arguments and return conventions:
 
 plus the batched form the GPU wants: `mel_batch(pcm[B, n]) -> torch.Tensor [B, 1, 80, 32]` on the device.
 
-`augment_audio` (train-only librosa pitch-shift / time-stretch) is out of scope and raises.
+  augment_audio(audio)        -> time shift / pitch shift / time stretch / noise, each with probability 0.8
+                                 (random draws from python `random` in the reference's order)  <- HIP kernels KA
 `load_audio` decodes PCM / float WAV with the standard library and resamples with scipy's polyphase
 filter -- NOT librosa's decoder + soxr resampler; moving decode+resample to the GPU is the first
 "next" row.
@@ -23,7 +24,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .config import AudioConfig, check_audio_config
+from .config import AudioConfig, AugmentationConfig, check_audio_config
 
 
 def _parse_wav(data: bytes):
@@ -138,9 +139,41 @@ class AudioProcessor:
         pcm = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).unsqueeze(0).to(self._dev())
         return ops.logmel(pcm, False)[0, 0].cpu().numpy()
 
-    def augment_audio(self, audio, config=None):
-        raise NotImplementedError("augment_audio (train-only librosa pitch-shift/time-stretch, "
-                                  "wakeword_training_script.py:103-123) is outside the accelerated inference path")
+    def draw_augment_plan(self, config=AugmentationConfig, length=None):
+        """The random draws of augment_audio (:103-123) in the reference's order -> one plan dict.
+        pad_or_truncate's crop start (:116-117) is drawn here too, right after the speed factor."""
+        sr = self.config.SAMPLE_RATE
+        n = length or int(sr * self.config.DURATION)
+        plan = {"shift": 0, "n_steps": None, "rate": None, "crop": 0, "sigma": 0.0, "seed": 0}
+        if random.random() < config.AUGMENTATION_PROB:
+            plan["shift"] = int(random.uniform(-config.TIME_SHIFT_MAX, config.TIME_SHIFT_MAX) * sr)
+        if random.random() < config.AUGMENTATION_PROB:
+            plan["n_steps"] = random.uniform(-config.PITCH_SHIFT_MAX, config.PITCH_SHIFT_MAX)
+        if random.random() < config.AUGMENTATION_PROB:
+            plan["rate"] = random.uniform(config.SPEED_CHANGE_MIN, config.SPEED_CHANGE_MAX)
+            stretched = int(round(n / plan["rate"]))
+            if stretched > n:
+                plan["crop"] = random.randint(0, stretched - n)
+        if random.random() < config.AUGMENTATION_PROB:
+            plan["sigma"] = float(config.NOISE_FACTOR)
+            plan["seed"] = random.getrandbits(32)
+        return plan
+
+    def augment_batch(self, pcm, plans=None, config=AugmentationConfig) -> torch.Tensor:
+        """pcm [B, 16000] (ndarray or tensor) -> augmented device tensor [B, 16000]; one plan per clip (drawn here if None)."""
+        t = torch.as_tensor(pcm, dtype=torch.float32)
+        if t.device.type != "cuda":
+            t = t.to(self._dev(), non_blocking=True)
+        if plans is None:
+            plans = [self.draw_augment_plan(config, t.shape[1]) for _ in range(t.shape[0])]
+        return ops.augment(t, plans)
+
+    def augment_audio(self, audio, config=AugmentationConfig):
+        """[16000] samples -> augmented float32 ndarray [16000] (reference :103-123), on the GPU."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        if a.shape != (int(self.config.SAMPLE_RATE * self.config.DURATION),):
+            raise ValueError(f"augment_audio takes exactly one padded clip of 16000 samples, got {a.shape}")
+        return self.augment_batch(a[None, :], config=config)[0].cpu().numpy()
 
     def process_audio_file(self, file_path, augment=False):
         audio = self.load_audio(file_path)

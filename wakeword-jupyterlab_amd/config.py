@@ -2,7 +2,8 @@
 
 AudioConfig / ModelConfig : /root/reference/wakeword_training_script.py:29-43 (dup notebook cell 3)
 Config                    : /root/reference/wakeword_training/train_wakeword.py:16-25
-Only the fields the inference path reads are kept (training/augmentation configs are out of scope).
+AugmentationConfig        : /root/reference/wakeword_training_script.py:52-58
+Only the fields the accelerated path reads are kept (training hyper-parameters are out of scope).
 """
 
 
@@ -15,6 +16,15 @@ class AudioConfig:
     WIN_LENGTH = 2048
     FMIN = 0
     FMAX = 8000
+
+
+class AugmentationConfig:
+    AUGMENTATION_PROB = 0.8
+    NOISE_FACTOR = 0.15
+    TIME_SHIFT_MAX = 0.3
+    PITCH_SHIFT_MAX = 3
+    SPEED_CHANGE_MIN = 0.7
+    SPEED_CHANGE_MAX = 1.3
 
 
 class ModelConfig:            # WakewordModel (3 convs)

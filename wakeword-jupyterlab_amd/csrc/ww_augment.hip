@@ -1,0 +1,401 @@
+// KA: AudioProcessor.augment_audio on the GPU (training-side, feeds K1).
+//
+// Replaces /root/reference/wakeword_training_script.py:103-123, one plan (the caller's random draws) per clip:
+//     np.roll -> librosa.effects.pitch_shift -> librosa.effects.time_stretch + pad_or_truncate -> + N(0, sigma)
+// librosa.effects.time_stretch = istft(phase_vocoder(stft(y), rate), length=round(len/rate)), n_fft 2048 / hop 512 / Hann;
+// pitch_shift = resample(time_stretch(y, 2^(-n/12)), ratio) cut or zero-padded to the input length.
+//
+//   roll_kernel       out[i] = in[(i - shift) mod L]                        (also the copy into the work buffer)
+//   stft_kernel       one workgroup per clip, one frame per wave at a time: window, 1024-point complex FFT of the
+//                     packed real frame (ww_fft.h), real-input split -> D[frame][0..1024] complex64
+//   pv_kernel         phase vocoder: thread = bin, sequential over the output steps; librosa's arithmetic types are
+//                     kept (float32 magnitudes and phase accumulator, float64 phase advance) so that the accumulator
+//                     rounds the same way
+//   istft_kernel      Hermitian spectrum -> conj(Z) -> the same forward FFT -> frame; window; overlap-add in an LDS
+//                     buffer that holds the whole stretched clip, in frame order (one barrier per frame, the adds are
+//                     cheap); window sum-square normalisation, centre trim, crop / zero-pad
+//   resample_kernel   windowed-sinc interpolation at t = i / ratio (resampy 'kaiser_best' table in LDS): the stand-in
+//                     for librosa's soxr_hq (absent third-party library; parity unpinned)
+//   noise_kernel      + sigma * normal(seed, i), the build's counter-based generator (splitmix64 -> Box-Muller)
+// Clips whose plan switches a transform off skip its kernels (their blocks copy the data through).
+#include <cmath>
+#include <vector>
+
+#include "ww_fft.h"
+
+namespace ww {
+
+constexpr int kAugFrames = kFrames;                 // STFT frames of a 16000-sample clip (1 + 16000/512 = 32)
+constexpr int kAugMaxOut = 46;                      // phase-vocoder output steps: ceil(32 / rate), rate >= 32/46
+constexpr int kAugMaxLen = kNfft + kHop * (kAugMaxOut - 1);   // 25,088 samples of overlap-add buffer
+constexpr int kAugYStride = 25600;                  // stretched-clip scratch row
+constexpr int kSpec = kBins;                        // 1025 complex bins per spectrum row
+
+struct AugDev {            // one per clip, derived on the host from ww_augment_plan
+    int32_t shift;         // np.roll shift reduced to [0, L)
+    int32_t crop;          // crop start after time_stretch
+    int32_t p_out, p_len, p_res;   // pitch: PV steps, istft length, resampled length (0 = pitch off)
+    int32_t s_out, s_len;          // stretch: PV steps, istft length (0 = stretch off)
+    uint32_t seed;
+    double p_rate, p_ratio, s_rate;
+    float sigma;
+    float pad_;
+};
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roll_kernel(const float* __restrict__ in, int64_t stride, const AugDev* __restrict__ plan,
+                                                   float* __restrict__ out) {
+    const int clip = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kClip) return;
+    int src = i - plan[clip].shift;
+    src += src < 0 ? kClip : 0;
+    out[int64_t(clip) * kClip + i] = in[int64_t(clip) * stride + src];
+}
+
+// ------------------------------------------------------------------------------------------------
+// which = 0: pitch stage, 1: stretch stage (selects the on/off flag)
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, const AugDev* __restrict__ plan, int which,
+                                                   const LogmelTables* __restrict__ tb, float2* __restrict__ D) {
+    __shared__ __attribute__((aligned(16))) float slabs[4 * fft::kSlabFloats];
+    const int clip = blockIdx.x;
+    if ((which == 0 ? plan[clip].p_out : plan[clip].s_out) == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* slab = slabs + wave * fft::kSlabFloats;
+    const float2* slab2 = reinterpret_cast<const float2*>(slab);
+    const float* xc = x + int64_t(clip) * kClip;
+    const float4* win4 = reinterpret_cast<const float4*>(&tb->window[0]);
+    for (int frame = wave; frame < kAugFrames; frame += 4) {
+        float2 za[8], zb[8];
+        const int base = frame * kHop - kNfft / 2 + 4 * lane;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int idx = base + 256 * n1;                     // multiple of 4: the float4 is all inside or all outside
+            const float4 s = (idx >= 0 && idx < kClip) ? *reinterpret_cast<const float4*>(xc + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 w = win4[64 * n1 + lane];
+            za[n1] = make_float2(s.x * w.x, s.y * w.y);
+            zb[n1] = make_float2(s.z * w.z, s.w * w.w);
+        }
+        fft::wave_fft1024(za, zb, slab, tb, lane);
+        // real-input split: X[k] = E + W^k O, X[1024-k] = conj(E - W^k O), E = (Z[k] + conj Z[1024-k])/2, O = (Z[k] - conj Z[1024-k])/(2i)
+        float2* Dr = D + (int64_t(clip) * kAugFrames + frame) * kSpec;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;                         // 0..511
+            const float2 a = slab2[fft::zpos(k)], b = slab2[fft::zpos((1024 - k) & 1023)];
+            const float2 tw = tb->twr[k];
+            const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            const float2 o = make_float2(0.5f * (a.y + b.y), 0.5f * (b.x - a.x));
+            const float2 t = fft::cmul(o, tw);
+            Dr[k] = make_float2(e.x + t.x, e.y + t.y);
+            Dr[1024 - k] = make_float2(e.x - t.x, -(e.y - t.y));
+        }
+        if (lane == 0) { const float2 z = slab2[fft::zpos(512)]; Dr[512] = make_float2(z.x, -z.y); }
+        fft::lds_order();                                        // the slab is rewritten by the next frame
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 pv_col(const float2* __restrict__ Dc, int f, int k) {
+    return f < kAugFrames ? Dc[int64_t(f) * kSpec + k] : make_float2(0.f, 0.f);     // librosa pads two zero columns
+}
+
+__global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, const AugDev* __restrict__ plan, int which,
+                                                 float2* __restrict__ S) {
+#pragma clang fp contract(off)
+    const int clip = blockIdx.x;
+    const int n_out = which == 0 ? plan[clip].p_out : plan[clip].s_out;
+    if (n_out == 0) return;
+    const double rate = which == 0 ? plan[clip].p_rate : plan[clip].s_rate;
+    const float2* Dc = D + int64_t(clip) * kAugFrames * kSpec;
+    float2* Sc = S + int64_t(clip) * kAugMaxOut * kSpec;
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int k = threadIdx.x; k < kSpec; k += 256) {
+        const double phi = double(k) * two_pi * 0.25;            // hop * 2 pi k / n_fft
+        const float2 d0 = Dc[k];
+        float acc = atan2f(d0.y, d0.x);                          // np.angle(D[:, 0]): float32 accumulator
+        for (int t = 0; t < n_out; ++t) {
+            const double step = double(t) * rate;                // np.arange(0, n, rate)[t]
+            const int i0 = int(step);
+            const double alpha = step - double(i0);
+            const float2 c0 = pv_col(Dc, i0, k), c1 = pv_col(Dc, i0 + 1, k);
+            const float m0 = hypotf(c0.x, c0.y), m1 = hypotf(c1.x, c1.y);
+            const float mag = float(1.0 - alpha) * m0 + float(alpha) * m1;
+            float sn, cs;
+            sincosf(acc, &sn, &cs);
+            Sc[int64_t(t) * kSpec + k] = make_float2(cs * mag, sn * mag);
+            const float da = atan2f(c1.y, c1.x) - atan2f(c0.y, c0.x);
+            double dphase = double(da) - phi;
+            dphase = dphase - two_pi * rint(dphase / two_pi);
+            acc = float(double(acc) + (phi + dphase));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kIstftLds = (kAugMaxLen + 4 * fft::kSlabFloats) * int(sizeof(float));     // 133,184 B
+
+// dst[i], i < dst_len, = y[i + crop] (0 past the stretched length); clips with the stage off copy `passthru` instead.
+__global__ __launch_bounds__(256) void istft_kernel(const float2* __restrict__ S, const AugDev* __restrict__ plan, int which,
+                                                    const LogmelTables* __restrict__ tb, const float* __restrict__ passthru,
+                                                    float* __restrict__ dst, int64_t dst_stride) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ola = lds;                                            // [kAugMaxLen]
+    const int clip = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n_out = which == 0 ? plan[clip].p_out : plan[clip].s_out;
+    float* out = dst + int64_t(clip) * dst_stride;
+    if (n_out == 0) {
+        if (passthru)
+            for (int i = tid; i < kClip; i += 256) out[i] = passthru[int64_t(clip) * kClip + i];
+        return;
+    }
+    const int length = which == 0 ? plan[clip].p_len : plan[clip].s_len;
+    const int crop = which == 0 ? 0 : plan[clip].crop;
+    const int dst_len = which == 0 ? length : kClip;
+    int n_frames = (length + kNfft + kHop - 1) / kHop;           // ceil((length + n_fft) / hop)
+    n_frames = n_frames < n_out ? n_frames : n_out;
+    float* slab = lds + kAugMaxLen + wave * fft::kSlabFloats;
+    const float2* slab2 = reinterpret_cast<const float2*>(slab);
+    for (int i = tid; i < kAugMaxLen; i += 256) ola[i] = 0.f;
+    __syncthreads();
+    const float2* Sc = S + int64_t(clip) * kAugMaxOut * kSpec;
+    for (int r0 = 0; r0 < n_frames; r0 += 4) {
+        const int frame = r0 + wave;
+        const bool live = frame < n_frames;
+        if (live) {
+            const float2* X = Sc + int64_t(frame) * kSpec;
+            float2 za[8], zb[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int m = 128 * n1 + 2 * lane + q;       // 0..1023
+                    float2 xm = X[m], xp = X[1024 - m];
+                    if (m == 0) { xm.y = 0.f; xp.y = 0.f; }      // irfft ignores the imaginary parts of DC and Nyquist
+                    // E = (X[m] + conj X[M-m])/2, O = (X[m] - conj X[M-m])/2 * conj(W^m), Z = E + iO; FFT input conj(Z)
+                    const float2 e = make_float2(0.5f * (xm.x + xp.x), 0.5f * (xm.y - xp.y));
+                    const float2 d = make_float2(0.5f * (xm.x - xp.x), 0.5f * (xm.y + xp.y));
+                    const float2 w = tb->twr[m];
+                    const float2 o = fft::cmul(d, make_float2(w.x, -w.y));
+                    const float2 zc = make_float2(e.x - o.y, -(e.y + o.x));
+                    if (q == 0) za[n1] = zc; else zb[n1] = zc;
+                }
+            fft::wave_fft1024(za, zb, slab, tb, lane);          // F = FFT(conj Z); z[n] = conj(F[n]) / 1024
+        }
+        // overlap-add in frame order: wave s adds in sub-step s
+        for (int s = 0; s < 4; ++s) {
+            if (wave == s && live) {
+                float2* o2 = reinterpret_cast<float2*>(ola + frame * kHop);
+                const float2* w2 = reinterpret_cast<const float2*>(&tb->window[0]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int n = lane + 64 * i;
+                    const float2 f = slab2[fft::zpos(n)];
+                    const float2 w = w2[n];
+                    float2 acc = o2[n];
+                    acc.x += w.x * (f.x * (1.0f / 1024.0f));
+                    acc.y += w.y * (-f.y * (1.0f / 1024.0f));
+                    o2[n] = acc;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // window sum-square at sample n of the padded signal, float32 in frame order as librosa accumulates it
+    for (int i = tid; i < dst_len; i += 256) {
+        const int src = i + crop;
+        float v = 0.f;
+        if (src < length) {
+            const int n = src + kNfft / 2;
+            v = n < kAugMaxLen ? ola[n] : 0.f;
+            int f0 = (n - kNfft + kHop) / kHop;                  // first frame that covers n
+            f0 = f0 < 0 ? 0 : f0;
+            int f1 = n / kHop;
+            f1 = f1 < n_frames - 1 ? f1 : n_frames - 1;
+            float ws = 0.f;
+            for (int f = f0; f <= f1; ++f) { const float w = tb->window[n - f * kHop]; ws += w * w; }
+            if (ws > 1.17549435e-38f) v = v / ws;
+        }
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kKbZeros = 64, kKbTable = 512;
+constexpr int kKbLen = kKbZeros * kKbTable + 1;                  // 32,769 table entries
+
+// One workgroup of 1024 threads per clip; the half-window lives in LDS (128 KiB).  Pitch-off clips copy through.
+__global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict__ Y, const AugDev* __restrict__ plan,
+                                                        const LogmelTables* __restrict__ tb, const float* __restrict__ passthru,
+                                                        float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];   // [kKbLen + 3]
+    const int clip = blockIdx.x, tid = threadIdx.x;
+    float* o = out + int64_t(clip) * kClip;
+    if (plan[clip].p_out == 0) {
+        for (int i = tid; i < kClip; i += 1024) o[i] = passthru[int64_t(clip) * kClip + i];
+        return;
+    }
+    for (int i = tid; i < kKbLen; i += 1024) tab[i] = tb->kaiser_best[i];
+    if (tid < 3) tab[kKbLen + tid] = tb->kaiser_best[kKbLen - 1];     // np.diff(win) is padded with a 0
+    __syncthreads();
+    const double ratio = plan[clip].p_ratio;
+    const double scale = ratio < 1.0 ? ratio : 1.0;
+    const int index_step = int(scale * kKbTable);
+    const int n_orig = plan[clip].p_len, n_res = plan[clip].p_res;
+    const float* y = Y + int64_t(clip) * kAugYStride;
+    const double inv = 1.0 / ratio;
+    for (int t = tid; t < kClip; t += 1024) {
+        double acc = 0.0;
+        const double time_register = double(t) * inv;
+        const int n = int(time_register);
+        if (t < n_res && n < n_orig) {
+            double frac = scale * (time_register - double(n));
+            double index_frac = frac * kKbTable;
+            int offset = int(index_frac);
+            double eta = index_frac - double(offset);
+            int i_max = (kKbLen - offset) / index_step;
+            i_max = i_max < n + 1 ? i_max : n + 1;
+            for (int i = 0; i < i_max; ++i) {
+                const int idx = offset + i * index_step;
+                const double w0 = double(tab[idx]), w1 = double(tab[idx + 1]);
+                acc += (w0 + eta * (w1 - w0)) * double(y[n - i]);
+            }
+            frac = scale - frac;
+            index_frac = frac * kKbTable;
+            offset = int(index_frac);
+            eta = index_frac - double(offset);
+            int k_max = (kKbLen - offset) / index_step;
+            k_max = k_max < n_orig - n - 1 ? k_max : n_orig - n - 1;
+            for (int k = 0; k < k_max; ++k) {
+                const int idx = offset + k * index_step;
+                const double w0 = double(tab[idx]), w1 = double(tab[idx + 1]);
+                acc += (w0 + eta * (w1 - w0)) * double(y[n + k + 1]);
+            }
+            if (ratio < 1.0) acc *= ratio;
+        }
+        o[t] = float(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ in, const AugDev* __restrict__ plan,
+                                                    float* __restrict__ out, int64_t out_stride) {
+    const int clip = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kClip) return;
+    float v = in[int64_t(clip) * kClip + i];
+    const float sigma = plan[clip].sigma;
+    if (sigma != 0.f) {
+        const uint64_t seed = plan[clip].seed;
+        const uint64_t k1 = mix64(seed * 0x9E3779B97F4A7C15ull + 1ull * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
+        const uint64_t k2 = mix64(seed * 0x9E3779B97F4A7C15ull + 2ull * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
+        const uint64_t j = uint64_t(i) + 1ull;
+        const double u1 = (double(uint32_t(mix64(k1 + j * 0x9E3779B97F4A7C15ull) >> 32)) + 0.5) * (1.0 / 4294967296.0);
+        const double u2 = (double(uint32_t(mix64(k2 + j * 0x9E3779B97F4A7C15ull) >> 32)) + 0.5) * (1.0 / 4294967296.0);
+        const double nrm = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+        v = float(double(v) + double(sigma) * nrm);
+    }
+    out[int64_t(clip) * out_stride + i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int64_t up256(int64_t b) { return (b + 255) & ~int64_t(255); }
+
+int64_t augment_workspace_bytes(int64_t n) {
+    return up256(n * int64_t(sizeof(AugDev))) + 2 * up256(n * int64_t(kClip) * 4) + up256(n * int64_t(kAugFrames) * kSpec * 8) +
+           up256(n * int64_t(kAugMaxOut) * kSpec * 8) + up256(n * int64_t(kAugYStride) * 4);
+}
+
+int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment_plan* plans_host, float* out,
+                   int64_t out_stride, void* workspace, hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    const LogmelTables* tb = device_tables();
+    if (!tb) return WW_EHIP;
+    // derive the per-clip records (librosa's lengths are host arithmetic: len(np.arange), round, ceil)
+    std::vector<AugDev> host(static_cast<size_t>(n));
+    bool any_pitch = false, any_stretch = false;
+    for (int64_t c = 0; c < n; ++c) {
+        const ww_augment_plan& p = plans_host[c];
+        AugDev d = {};
+        int64_t sh = int64_t(p.shift) % kClip;
+        d.shift = int32_t(sh < 0 ? sh + kClip : sh);
+        d.sigma = p.noise_sigma;
+        d.seed = p.noise_seed;
+        if (!(p.noise_sigma >= 0.f)) return fail(WW_EINVAL, "plan %lld: noise_sigma must be >= 0", (long long)c);
+        auto steps = [](double rate) { return int(std::ceil(double(kAugFrames) / rate)); };
+        auto check = [&](double rate, const char* what) {
+            if (!(rate > 0.0) || steps(rate) > kAugMaxOut || steps(rate) < 2)
+                return fail(WW_EUNSUPPORTED, "plan %lld: %s rate %g outside [%g, 32)", (long long)c, what, rate, double(kAugFrames) / kAugMaxOut);
+            return int(WW_OK);
+        };
+        if (p.pitch_rate != 0.0) {
+            if (int rc = check(p.pitch_rate, "pitch")) return rc;
+            d.p_rate = p.pitch_rate;
+            d.p_out = steps(p.pitch_rate);
+            d.p_len = int32_t(std::nearbyint(double(kClip) / p.pitch_rate));      // Python round(): half to even
+            d.p_ratio = double(WW_SAMPLE_RATE) / (double(WW_SAMPLE_RATE) / p.pitch_rate);
+            d.p_res = int32_t(std::ceil(double(d.p_len) * d.p_ratio));
+            any_pitch = true;
+        }
+        if (p.stretch_rate != 0.0) {
+            if (int rc = check(p.stretch_rate, "stretch")) return rc;
+            d.s_rate = p.stretch_rate;
+            d.s_out = steps(p.stretch_rate);
+            d.s_len = int32_t(std::nearbyint(double(kClip) / p.stretch_rate));
+            const int over = d.s_len > kClip ? d.s_len - kClip : 0;
+            if (p.crop_start < 0 || p.crop_start > over)
+                return fail(WW_EINVAL, "plan %lld: crop_start %d outside [0, %d]", (long long)c, p.crop_start, over);
+            d.crop = p.crop_start;
+            any_stretch = true;
+        }
+        host[size_t(c)] = d;
+    }
+    char* w = static_cast<char*>(workspace);
+    AugDev* plan = reinterpret_cast<AugDev*>(w); w += up256(n * int64_t(sizeof(AugDev)));
+    float* bufA = reinterpret_cast<float*>(w); w += up256(n * int64_t(kClip) * 4);
+    float* bufB = reinterpret_cast<float*>(w); w += up256(n * int64_t(kClip) * 4);
+    float2* D = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugFrames) * kSpec * 8);
+    float2* S = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugMaxOut) * kSpec * 8);
+    float* Y = reinterpret_cast<float*>(w);
+    WW_HIP(hipMemcpyAsync(plan, host.data(), size_t(n) * sizeof(AugDev), hipMemcpyHostToDevice, stream));
+    WW_HIP(hipStreamSynchronize(stream));     // `host` is pageable and dies with this frame
+
+    static bool attr[64] = {};
+    int dev = 0;
+    WW_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIstftLds));
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (kKbLen + 3) * 4));
+        attr[dev] = true;
+    }
+    const dim3 egrid((kClip + 255) / 256, unsigned(n));
+    hipLaunchKernelGGL(roll_kernel, egrid, dim3(256), 0, stream, pcm, stride, plan, bufA);
+    float* cur = bufA;
+    float* other = bufB;
+    if (any_pitch) {
+        hipLaunchKernelGGL(stft_kernel, dim3(unsigned(n)), dim3(256), 0, stream, cur, plan, 0, tb, D);
+        hipLaunchKernelGGL(pv_kernel, dim3(unsigned(n)), dim3(256), 0, stream, D, plan, 0, S);
+        hipLaunchKernelGGL(istft_kernel, dim3(unsigned(n)), dim3(256), kIstftLds, stream, S, plan, 0, tb,
+                           static_cast<const float*>(nullptr), Y, int64_t(kAugYStride));
+        hipLaunchKernelGGL(resample_kernel, dim3(unsigned(n)), dim3(1024), (kKbLen + 3) * 4, stream, Y, plan, tb, cur, other);
+        float* t = cur; cur = other; other = t;
+    }
+    if (any_stretch) {
+        hipLaunchKernelGGL(stft_kernel, dim3(unsigned(n)), dim3(256), 0, stream, cur, plan, 1, tb, D);
+        hipLaunchKernelGGL(pv_kernel, dim3(unsigned(n)), dim3(256), 0, stream, D, plan, 1, S);
+        hipLaunchKernelGGL(istft_kernel, dim3(unsigned(n)), dim3(256), kIstftLds, stream, S, plan, 1, tb, cur, other, int64_t(kClip));
+        float* t = cur; cur = other; other = t;
+    }
+    hipLaunchKernelGGL(noise_kernel, egrid, dim3(256), 0, stream, cur, plan, out, out_stride);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+}  // namespace ww

@@ -48,6 +48,9 @@ struct LogmelTables {
     int32_t piece_info[kPieces];  // (8m) | (output position << 16); output positions are filter-major
     int32_t filt_p0[kMels];       // first output position of filter f
     int32_t filt_cnt[kMels];      // number of pieces of filter f
+    // augmentation kernels (ww_augment.hip)
+    float2 twr[1024];             // W_2048^k, k = 0..1023
+    float kaiser_best[32772];     // resampler half-window: 64 zero crossings x 512 + 1 entries (+3 pad)
 };
 
 void build_mel_filterbank(float* out /*[80][1025]*/);
@@ -92,6 +95,10 @@ PackedLayout packed_layout(int n_conv);
 int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
                   const int32_t* ring_pos /*nullable: streaming ring start per launch*/, int64_t ring_len,
                   float* logmel, hipStream_t stream);
+int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment_plan* plans_host, float* out,
+                   int64_t out_stride, void* workspace, hipStream_t stream);
+int64_t augment_workspace_bytes(int64_t n);
+void build_kaiser_best(float* out /*[32769]*/);
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
                     float* pooled, hipStream_t stream);
 // conv math: 0 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split (3 x v_mfma_f32_32x32x16_f16 per product block)

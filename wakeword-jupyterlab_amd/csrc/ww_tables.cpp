@@ -59,6 +59,34 @@ void build_hann(double* w) {
     for (int n = 0; n < kNfft; ++n) w[n] = 0.5 - 0.5 * std::cos(2.0 * M_PI * n / kNfft);
 }
 
+// Modified Bessel function I0 by its power series (x <= 15: 40 terms reach double precision).
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = 0.25 * x * x;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / (double(k) * double(k));
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+// resampy.filters.sinc_window(num_zeros=64, precision=9, window=kaiser(beta), rolloff): the right half of
+// kaiser(2n+1, beta) * rolloff * sinc(rolloff * x), x = linspace(0, 64, n + 1), n = 64 * 512.
+void build_kaiser_best(float* out) {
+    const int n = 64 * 512;
+    const double beta = 14.769656459379492, rolloff = 0.9475937167399596;
+    const double i0b = bessel_i0(beta);
+    for (int i = 0; i <= n; ++i) {
+        const double x = 64.0 * double(i) / double(n);
+        const double a = M_PI * rolloff * x;
+        const double sinc = i == 0 ? 1.0 : std::sin(a) / a;
+        const double r = double(i) / double(n);
+        const double taper = bessel_i0(beta * std::sqrt(std::fmax(0.0, 1.0 - r * r))) / i0b;
+        out[i] = float(taper * rolloff * sinc);
+    }
+}
+
 static float2 twiddle(int N, long e) {   // W_N^e = exp(-2*pi*i*e/N), argument reduced exactly
     e %= N;
     const double a = -2.0 * M_PI * double(e) / double(N);
@@ -75,6 +103,8 @@ int build_logmel_tables(LogmelTables* t) {
     for (int k2 = 1; k2 < 8; ++k2)
         for (int n = 0; n < 16; ++n) t->tw2[k2 - 1][n] = twiddle(128, long(n) * k2);
     for (int k = 0; k < 512; ++k) t->twp[k] = twiddle(2048, k == 0 ? 512 : k);
+    for (int k = 0; k < 1024; ++k) t->twr[k] = twiddle(2048, k);
+    build_kaiser_best(t->kaiser_best);
 
     std::vector<float> M(size_t(kMels) * kBins);
     build_mel_filterbank(M.data());
@@ -277,6 +307,12 @@ const char* ww_last_error(void) { return ww::last_error(); }
 int ww_mel_filterbank_host(float* out_host) {
     if (!out_host) return fail(WW_EINVAL, "null output");
     build_mel_filterbank(out_host);
+    return WW_OK;
+}
+
+int ww_kaiser_best_host(float* out_host) {
+    if (!out_host) return fail(WW_EINVAL, "null output pointer");
+    build_kaiser_best(out_host);
     return WW_OK;
 }
 

@@ -9,6 +9,9 @@ log-mel kernel once per batch, yielding device tensors with `default_collate`'s 
 One deliberate deviation: when a file fails to load the reference substitutes `np.zeros((80, 31))`
 (:210-211), whose width (31) differs from real items (32) and makes `default_collate` raise.  Here the
 substitute is zeros of the real width, [80, 32].
+
+`augment=True` (the training split, :456) runs AudioProcessor.augment_audio's transforms on the GPU (kernels KA)
+between decode and log-mel: per item in `__getitem__`, per batch in `batches()`.
 """
 from __future__ import annotations
 
@@ -21,8 +24,6 @@ from .config import N_FRAMES
 
 class WakewordDataset(Dataset):
     def __init__(self, wakeword_files, negative_files, processor, augment=False, verbose=True):
-        if augment:
-            raise NotImplementedError("augment=True (training-only augmentation) is outside the accelerated path")
         self.wakeword_files = list(wakeword_files)
         self.negative_files = list(negative_files)
         self.processor = processor
@@ -55,6 +56,8 @@ class WakewordDataset(Dataset):
                 pcm, ok = self.processor.load_clips(paths)
                 pcm_dev = torch.from_numpy(pcm).to(dev)
             # both loaders already peak-normalised each file before the crop/pad, as the reference does (:131-133)
+            if self.augment:
+                pcm_dev = self.processor.augment_batch(pcm_dev)          # process_audio_file :134-135
             data = self.processor.mel_batch(pcm_dev, normalize=False)
             if not ok.all():
                 data[torch.from_numpy(~ok).to(dev)] = 0.0

@@ -257,3 +257,44 @@ import os as _os  # noqa: E402
 
 if _os.environ.get("WW_CONV_MATH"):
     set_conv_math(_os.environ["WW_CONV_MATH"])
+
+
+# ---- KA: augmentation ------------------------------------------------------------------
+def augment(pcm: torch.Tensor, plans) -> torch.Tensor:
+    """pcm [B, 16000] float32 on the GPU + one plan per clip -> augmented [B, 16000] (ww_augment_f32).
+
+    `plans`: a ctypes array of _native.AugmentPlan, or a list of dicts with the keys of oracle-style plans
+    (shift, n_steps | pitch_rate, rate, crop, sigma, seed); see AudioProcessor.draw_augment_plan."""
+    import ctypes as C
+    if pcm.device.type != "cuda":
+        raise RuntimeError("augment: pcm must live on the MI355X (no CPU fallback)")
+    if pcm.dtype != torch.float32 or pcm.dim() != 2 or pcm.shape[1] != 16000:
+        raise ValueError(f"augment: expected float32 [B, 16000], got {pcm.dtype} {tuple(pcm.shape)}")
+    pcm = pcm.contiguous()
+    B = pcm.shape[0]
+    if not isinstance(plans, C.Array):
+        arr = (nat.AugmentPlan * max(1, B))()
+        if len(plans) != B:
+            raise ValueError(f"augment: {len(plans)} plans for {B} clips")
+        for i, p in enumerate(plans):
+            a = arr[i]
+            a.shift = int(p.get("shift", 0))
+            a.crop_start = int(p.get("crop", 0))
+            n_steps = p.get("n_steps")
+            a.pitch_rate = float(p["pitch_rate"]) if p.get("pitch_rate") else (2.0 ** (-float(n_steps) / 12.0) if n_steps is not None else 0.0)
+            a.stretch_rate = float(p["rate"]) if p.get("rate") else 0.0
+            a.noise_sigma = float(p.get("sigma", 0.0))
+            a.noise_seed = int(p.get("seed", 0)) & 0xFFFFFFFF
+        plans = arr
+    elif len(plans) < B:
+        raise ValueError(f"augment: {len(plans)} plans for {B} clips")
+    out = torch.empty_like(pcm)
+    if B == 0:
+        return out
+    with torch.cuda.device(pcm.device):
+        ws_bytes = nat.check(nat.lib.ww_augment_workspace_bytes(B))
+        ws = torch.empty(ws_bytes, device=pcm.device, dtype=torch.uint8)
+        nat.check(nat.lib.ww_augment_f32(C.c_void_p(pcm.data_ptr()), B, pcm.stride(0), plans, C.c_void_p(out.data_ptr()),
+                                         C.c_void_p(ws.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ws.record_stream(torch.cuda.current_stream())
+    return out
