@@ -4,7 +4,9 @@ PARITY UNPINNED against librosa / soxr / numpy's RNG themselves (none can be run
 the oracle restates librosa 0.10.1's phase vocoder and stands in for the resampler and the noise stream (see its header).
 Tolerances: time shift exact; noise 1e-6; the phase-vocoder paths are float32 FFTs against the oracle's float64 ones
 and carry librosa's float32 phase accumulator (values up to ~7e4 rad, one ulp = 0.008 rad), so a last-bit difference in an
-atan2 can move one bin's phase by an ulp: max |err| <= 2e-3 of the clip's peak and rms err <= 2e-4 of its rms.
+atan2 or in a weak STFT bin moves that bin's phase by an ulp.  tests/test_oracle_augment.py measures that floor on the
+oracle itself (float32-level noise in D -> ~1e-4..3e-4 of the output's rms); the bounds here are a small multiple of it:
+max |err| <= 3e-3 of the clip's peak and rms err <= 1e-3 of its rms per vocoder pass (twice that for pitch + stretch).
 """
 import random
 
@@ -32,7 +34,7 @@ def _run(x, plans):
     return ops.augment(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(DEV), plans).cpu().numpy()
 
 
-def _check(got, want, max_rel=2e-3, rms_rel=2e-4):
+def _check(got, want, max_rel=3e-3, rms_rel=1e-3):
     assert got.shape == want.shape and got.dtype == np.float32
     err = got.astype(np.float64) - want.astype(np.float64)
     peak, rms = np.abs(want).max(), np.sqrt((want.astype(np.float64) ** 2).mean())
@@ -102,7 +104,7 @@ def test_full_plans_mixed_batch():
     plans[2] = dict(plans[2], rate=None, crop=0)
     got = _run(x, plans)
     for i in range(n):
-        _check(got[i], ao.augment(x[i], plans[i]), max_rel=4e-3, rms_rel=4e-4)    # two vocoder passes in sequence
+        _check(got[i], ao.augment(x[i], plans[i]), max_rel=6e-3, rms_rel=2e-3)    # two vocoder passes in sequence
 
 
 def test_rejects_bad_plans_before_launching():
@@ -128,7 +130,7 @@ def test_audio_processor_augment_audio_and_dataset(tmp_path):
     assert isinstance(z, np.ndarray) and z.shape == (16000,) and z.dtype == np.float32 and np.isfinite(z).all()
     random.seed(7)
     plan = proc.draw_augment_plan()
-    _check(z, ao.augment(y, plan), max_rel=4e-3, rms_rel=4e-4)
+    _check(z, ao.augment(y, plan), max_rel=6e-3, rms_rel=2e-3)
     with pytest.raises(ValueError):
         proc.augment_audio(y[:100])
     # WakewordDataset(augment=True): per item and per batch, shapes as the reference's

@@ -44,6 +44,20 @@ def test_phase_vocoder_rate_one_is_identity_and_lengths():
         assert len(ao.time_stretch(y, rate)) == int(round(16000 / rate))
 
 
+def test_phase_vocoder_conditioning_sets_the_gpu_tolerance():
+    """librosa's float32 phase accumulator makes time_stretch sensitive to float32-level noise in the STFT: perturbing D by
+    2e-7 of its peak (what a float32 FFT does) moves the OUTPUT by ~1e-4 of its rms.  The GPU tests' tolerances
+    (tests/test_gpu_augment.py: rms 1e-3, max 3e-3 of the peak per vocoder pass) are a small multiple of this floor."""
+    rng = np.random.default_rng(0)
+    y = _clip(3) / np.abs(_clip(3)).max()
+    D = ao.stft(y)
+    base = ao.istft(ao.phase_vocoder(D, 0.8), 20000).astype(np.float64)
+    Dp = (D + 2e-7 * np.abs(D).max() * (rng.standard_normal(D.shape) + 1j * rng.standard_normal(D.shape))).astype(np.complex64)
+    pert = ao.istft(ao.phase_vocoder(Dp, 0.8), 20000).astype(np.float64)
+    rel = np.sqrt(((pert - base) ** 2).mean()) / np.sqrt((base ** 2).mean())
+    assert 3e-5 < rel < 1e-3
+
+
 def test_pitch_shift_moves_a_tone():
     t = np.arange(16000) / 16000.0
     tone = np.sin(2 * np.pi * 440.0 * t).astype(np.float32)
