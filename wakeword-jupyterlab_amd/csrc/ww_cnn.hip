@@ -305,26 +305,26 @@ __device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restr
 // conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
 //   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
 // The log-mel tile is kept as two f16 planes (hi, lo) so the patch operand needs no conversions.
-// Producer pw handles tile rows q = pw, pw + 4, pw + 8 (< 10) of the band, all three in flight together.
+// A producer runs the rows qa, qb and (if >= 0) qc of the band's tile, all in flight together.
 __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const _Float16* __restrict__ ml,
                                                 char* __restrict__ act, half8 a1h, half8 a1l, int y0, int width,
-                                                int pw, int lane) {
+                                                int qa, int qb, int qc, int lane) {
     const int x = lane & 31, h = lane >> 5;
     const bool full = width == kW;                       // uniform: skips the per-value column mask
-    const bool third = pw + 8 < kARows;                  // uniform: producers 0 and 1 own three rows
+    const bool third = qc >= 0;                          // uniform
     Conv1Row r0, r1, r2;
-    conv1_row_gather(r0, mh, ml, y0 - 1 + pw, x, h);
-    conv1_row_gather(r1, mh, ml, y0 - 1 + pw + 4, x, h);
-    if (third) conv1_row_gather(r2, mh, ml, y0 - 1 + pw + 8, x, h);
+    conv1_row_gather(r0, mh, ml, y0 - 1 + qa, x, h);
+    conv1_row_gather(r1, mh, ml, y0 - 1 + qb, x, h);
+    if (third) conv1_row_gather(r2, mh, ml, y0 - 1 + qc, x, h);
     conv1_row_mfma(r0, a1h, a1l);
     conv1_row_mfma(r1, a1h, a1l);
     if (third) conv1_row_mfma(r2, a1h, a1l);
-    char* rec = act + (pw * kRS + x + 1) * kPos16 + h * 32;            // this lane's 16 channels 16h..16h+15
+    char* rec = act + (x + 1) * kPos16 + h * 32;                       // this lane's 16 channels 16h..16h+15
     const bool col_ok = x < width;
     // rows outside the image are conv2's zero padding: `keep` false zeroes them (never `full` for such a row)
-    conv1_row_store(r0, rec, col_ok && r0.ok, full && r0.ok);
-    conv1_row_store(r1, rec + 4 * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
-    if (third) conv1_row_store(r2, rec + 8 * kRS * kPos16, col_ok && r2.ok, full && r2.ok);
+    conv1_row_store(r0, rec + qa * kRS * kPos16, col_ok && r0.ok, full && r0.ok);
+    conv1_row_store(r1, rec + qb * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
+    if (third) conv1_row_store(r2, rec + qc * kRS * kPos16, col_ok && r2.ok, full && r2.ok);
 }
 
 #ifdef WW_STAMPS
@@ -394,10 +394,28 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             pl[(y + 1) * kMelHRS + xx + 1] = static_cast<_Float16>(v - static_cast<float>(hi));
         }
     };
+    // conv1 of step g (clip g / 10, band g % 10) into tile g & 1.  Band 0 computes all ten rows (row 0 is the zero
+    // padding above the image); for the other bands tile rows 0 and 1 (image rows 8b - 1, 8b) are the previous band's
+    // rows 8 and 9, still in the other tile: they are COPIED (544 x 16 bytes over the four producer waves) and only
+    // eight rows are computed, two per producer.
     auto produce = [&](int g) {
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
         const _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
-        conv1_rows_mfma(ph, ph + kMelHPlane, act0 + (g & 1) * kH16Act, a1h, a1l, band * kBand, width, wave - 8, lane);
+        char* tile = act0 + (g & 1) * kH16Act;
+        const int pw = wave - 8;
+        if (band == 0) {
+            conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, 0, width, pw, pw + 4, pw + 8 < kARows ? pw + 8 : -1, lane);
+            return;
+        }
+        conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, band * kBand, width, 2 + pw, 6 + pw, -1, lane);
+        const char* prev = act0 + ((g & 1) ^ 1) * kH16Act + 8 * kH16Row;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = ptid + 256 * i;                              // chunk: position c >> 3 (2 rows x 34), 16-byte part c & 7
+            if (c < 2 * kRS * 8)
+                *reinterpret_cast<u32x4*>(tile + (c >> 3) * kPos16 + (c & 7) * 16) =
+                    *reinterpret_cast<const u32x4*>(prev + (c >> 3) * kPos16 + (c & 7) * 16);
+        }
     };
     auto write_pooled = [&](int k) {     // wave 0: pooled[clip][co], co = lane: sum the two row groups
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
@@ -470,11 +488,17 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                         }
                 }
             };
-            half8 ah = frag(0, 0), al = frag(0, 1);
+            // fragments run TWO steps ahead of their MFMAs in a 3-deep register ring; the scheduling barriers keep the
+            // compiler from sinking the ds_reads back down to their first use (it does, to save 8 VGPRs, and then every
+            // step waits out a full LDS round trip)
+            half8 fh[3], fl[3];
+            fh[0] = frag(0, 0); fl[0] = frag(0, 1);
+            fh[1] = frag(1, 0); fl[1] = frag(1, 1);
 #pragma unroll
             for (int it = 0; it < 36; ++it) {
-                half8 ahn = ah, aln = al;
-                if (it + 1 < 36) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
+                if (it + 2 < 36) { fh[(it + 2) % 3] = frag(it + 2, 0); fl[(it + 2) % 3] = frag(it + 2, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const half8 ah = fh[it % 3], al = fl[it % 3];
                 const int q = it / 6, dx = (it / 2) % 3, ch = it & 1;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
@@ -485,8 +509,8 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                     acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[r][ch], 0, 0, 0);
                     acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[r][ch], 0, 0, 0);
                 }
-                ah = ahn; al = aln;
                 if (it % 6 == 5 && q >= 2) epilogue_row(q - 2);
+                __builtin_amdgcn_sched_barrier(0);
             }
             CSTAMP(1);
             if (POOL && band == kH / kBand - 1) {
