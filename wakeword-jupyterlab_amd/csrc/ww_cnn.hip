@@ -305,26 +305,23 @@ __device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restr
 // conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
 //   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
 // The log-mel tile is kept as two f16 planes (hi, lo) so the patch operand needs no conversions.
-// A producer runs the rows qa, qb and (if >= 0) qc of the band's tile, all in flight together.
+// A producer runs the rows qa and (if >= 0) qb of the band's tile side by side.
 __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const _Float16* __restrict__ ml,
                                                 char* __restrict__ act, half8 a1h, half8 a1l, int y0, int width,
-                                                int qa, int qb, int qc, int lane) {
+                                                int qa, int qb, int lane) {
     const int x = lane & 31, h = lane >> 5;
     const bool full = width == kW;                       // uniform: skips the per-value column mask
-    const bool third = qc >= 0;                          // uniform
-    Conv1Row r0, r1, r2;
+    const bool second = qb >= 0;                         // uniform
+    Conv1Row r0, r1;
     conv1_row_gather(r0, mh, ml, y0 - 1 + qa, x, h);
-    conv1_row_gather(r1, mh, ml, y0 - 1 + qb, x, h);
-    if (third) conv1_row_gather(r2, mh, ml, y0 - 1 + qc, x, h);
+    if (second) conv1_row_gather(r1, mh, ml, y0 - 1 + qb, x, h);
     conv1_row_mfma(r0, a1h, a1l);
-    conv1_row_mfma(r1, a1h, a1l);
-    if (third) conv1_row_mfma(r2, a1h, a1l);
+    if (second) conv1_row_mfma(r1, a1h, a1l);
     char* rec = act + (x + 1) * kPos16 + h * 32;                       // this lane's 16 channels 16h..16h+15
     const bool col_ok = x < width;
     // rows outside the image are conv2's zero padding: `keep` false zeroes them (never `full` for such a row)
     conv1_row_store(r0, rec + qa * kRS * kPos16, col_ok && r0.ok, full && r0.ok);
-    conv1_row_store(r1, rec + qb * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
-    if (third) conv1_row_store(r2, rec + qc * kRS * kPos16, col_ok && r2.ok, full && r2.ok);
+    if (second) conv1_row_store(r1, rec + qb * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
 }
 
 #ifdef WW_STAMPS
@@ -403,11 +400,11 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         const _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
         char* tile = act0 + (g & 1) * kH16Act;
         const int pw = wave - 8;
+        conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, band * kBand, width, 2 + pw, 6 + pw, lane);
         if (band == 0) {
-            conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, 0, width, pw, pw + 4, pw + 8 < kARows ? pw + 8 : -1, lane);
+            if (pw < 2) conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, 0, width, pw, -1, lane);
             return;
         }
-        conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, band * kBand, width, 2 + pw, 6 + pw, -1, lane);
         const char* prev = act0 + ((g & 1) ^ 1) * kH16Act + 8 * kH16Row;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -436,10 +433,25 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     unsigned long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clast = 0;
     CSTAMP(7);
 #endif
+    // Two loops, one per role, with the same number of barriers: the consumers' resident B operands and accumulators
+    // are then not live in the producers' code (a single loop with a role branch makes the allocator keep both sets).
+    if (!consumer) {
+        for (int g = 0; g < steps; ++g) {
+            CSTAMP(0);
+            if (g + 1 < steps) {
+                produce(g + 1);
+                const int k1 = (g + 1) / (kH / kBand);
+                if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);
+                CSTAMP(3);
+            }
+            __syncthreads();
+            CSTAMP(4);
+        }
+    } else {
     for (int g = 0; g < steps; ++g) {
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
         CSTAMP(0);
-        if (consumer) {
+        {
             if (POOL && band == 0 && g > 0 && wave == 0) write_pooled(k - 1);
             const char* ap = act0 + (g & 1) * kH16Act + ((rg * 4) * kRS + pi) * kPos16 + kq * 16;
             f32x4 acc[4][2];
@@ -491,14 +503,18 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             // fragments run TWO steps ahead of their MFMAs in a 3-deep register ring; the scheduling barriers keep the
             // compiler from sinking the ds_reads back down to their first use (it does, to save 8 VGPRs, and then every
             // step waits out a full LDS round trip)
-            half8 fh[3], fl[3];
-            fh[0] = frag(0, 0); fl[0] = frag(0, 1);
-            fh[1] = frag(1, 0); fl[1] = frag(1, 1);
+#ifndef WW_K2_PF
+#define WW_K2_PF 2
+#endif
+            constexpr int PF = WW_K2_PF, RING = PF + 1;
+            half8 fh[RING], fl[RING];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) { fh[i] = frag(i, 0); fl[i] = frag(i, 1); }
 #pragma unroll
             for (int it = 0; it < 36; ++it) {
-                if (it + 2 < 36) { fh[(it + 2) % 3] = frag(it + 2, 0); fl[(it + 2) % 3] = frag(it + 2, 1); }
+                if (it + PF < 36) { fh[(it + PF) % RING] = frag(it + PF, 0); fl[(it + PF) % RING] = frag(it + PF, 1); }
                 __builtin_amdgcn_sched_barrier(0);
-                const half8 ah = fh[it % 3], al = fl[it % 3];
+                const half8 ah = fh[it % RING], al = fl[it % RING];
                 const int q = it / 6, dx = (it / 2) % 3, ch = it & 1;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
@@ -519,14 +535,10 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                 if (lane < 16) red[wave * 16 + lane] = p2;
             }
             CSTAMP(2);
-        } else if (g + 1 < steps) {
-            produce(g + 1);
-            const int k1 = (g + 1) / (kH / kBand);
-            if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);
-            CSTAMP(3);
         }
         __syncthreads();
         CSTAMP(4);
+    }
     }
     if (POOL && consumer && wave == 0 && steps > 0) write_pooled(my_clips - 1);
 #ifdef WW_STAMPS
