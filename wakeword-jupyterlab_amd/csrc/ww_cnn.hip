@@ -703,16 +703,21 @@ __global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restric
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[r][c][j] = 0.f;
-        // 72 fragment steps it = ((cb*3 + dx)*6 + q)*2 + ch, pipelined one step ahead
+        // 72 fragment steps it = ((cb*3 + dx)*6 + q)*2 + ch
         auto frag = [&](int it, int half) -> half8 {
             const int cb = it / 36, dx = (it / 12) % 3, q = (it / 2) % 6, ch = it & 1;
             return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + (q * kRS + 16 * ch + dx) * kRec3 + half * 128 + cb * 64));
         };
-        half8 ah = frag(0, 0), al = frag(0, 1);
+        // fragment ring two steps ahead of the MFMAs, pinned with scheduling barriers (see cnn2h16_kernel)
+        constexpr int PF = 2, RING = PF + 1;
+        half8 fh[RING], fl[RING];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) { fh[i] = frag(i, 0); fl[i] = frag(i, 1); }
 #pragma unroll
         for (int it = 0; it < 72; ++it) {
-            half8 ahn = ah, aln = al;
-            if (it + 1 < 72) { ahn = frag(it + 1, 0); aln = frag(it + 1, 1); }
+            if (it + PF < 72) { fh[(it + PF) % RING] = frag(it + PF, 0); fl[(it + PF) % RING] = frag(it + PF, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 ah = fh[it % RING], al = fl[it % RING];
             const int cb = it / 36, dx = (it / 12) % 3, q = (it / 2) % 6, ch = it & 1;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restric
                 acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[r][ch], 0, 0, 0);
                 acc[r][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[r][ch], 0, 0, 0);
             }
-            ah = ahn; al = aln;
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (band == 0) pool = 0.f;
 #pragma unroll
