@@ -250,12 +250,18 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
                 zb[n1] = make_float2(s.z * w.z, s.w * w.w);
             }
             // ---- pass 1: radix 8 over n1 (stride 128), twiddle W_1024^{n' k1}, store X1 ----
+            // Table operands are fetched as a group BEFORE the arithmetic they follow: written at their use, each load
+            // is issued right there and the wave pays one L1 / LDS round trip per twiddle.
+            float4 t1[7];
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) t1[k1 - 1] = tw1_4[(k1 - 1) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
             dft8(za);
             dft8(zb);
             slab4[lane] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) {
-                const float4 t = tw1_4[(k1 - 1) * 64 + lane];
+                const float4 t = t1[k1 - 1];
                 const float2 a = cmul(za[k1], make_float2(t.x, t.y));
                 const float2 b = cmul(zb[k1], make_float2(t.z, t.w));
                 slab4[k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)))] = make_float4(a.x, a.y, b.x, b.y);
@@ -274,7 +280,11 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
                     za[n2] = make_float2(v.x, v.y);
                     zb[n2] = make_float2(v.z, v.w);
                 }
+                float4 t2[7];
+#pragma unroll
+                for (int k2 = 1; k2 < 8; ++k2) t2[k2 - 1] = tw2_4[(k2 - 1) * 8 + jr];
                 lds_order();
+                __builtin_amdgcn_sched_barrier(0);
                 dft8(za);
                 dft8(zb);
                 // writer (k1, j), reader lane 8 k1 + k2, slot j ^ ((reader >> 1) & 7) = j ^ (4 (k1 & 1) + (k2 >> 1)):
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
                 for (int k2 = 0; k2 < 8; ++k2) {
                     float2 a = za[k2], b = zb[k2];
                     if (k2 > 0) {
-                        const float4 t = tw2_4[(k2 - 1) * 8 + jr];
+                        const float4 t = t2[k2 - 1];
                         a = cmul(a, make_float2(t.x, t.y));
                         b = cmul(b, make_float2(t.z, t.w));
                     }
@@ -314,6 +324,14 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             }
             lds_order();
             STAMP(2);
+            // mel-piece weights of this lane (L1 hits): issued ahead of the frame prefetch because vmcnt retires in
+            // order -- the mel stage then waits for them with the eight sample loads still in flight
+            float4 pw0[kPieceRounds], pw1[kPieceRounds];
+#pragma unroll
+            for (int c = 0; c < kPieceRounds; ++c) {
+                pw0[c] = pw4[c * kPieceSlots + lane];
+                pw1[c] = pw4[kPieces + c * kPieceSlots + lane];
+            }
             // next frame's samples: issued here, after the register-hungry FFT passes, and in flight under the
             // power / mel stages (about a third of the frame time, several times the HBM latency)
             {
@@ -336,11 +354,15 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
                     b[j] = zb_p[64 * (15 - j)];
                 }
                 if (lane == 0) { a[0] = slab2[512]; b[0] = a[0]; }
+                float2 twj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) twj[j] = twp_2[lane + 64 * j];
                 lds_order();
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = (j == 0 && lane == 0) ? 512 : lane + 64 * j;
-                    const float2 tw = twp_2[lane + 64 * j];
+                    const float2 tw = twj[j];
                     const float2 e = make_float2(0.5f * (a[j].x + b[j].x), 0.5f * (a[j].y - b[j].y));
                     const float2 o = make_float2(0.5f * (a[j].y + b[j].y), 0.5f * (b[j].x - a[j].x));   // (a - conj b)/(2i)
                     const float2 t = cmul(o, tw);
@@ -354,22 +376,29 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             STAMP(3);
             // ---- sparse mel of THIS wave's frame: lane = slot, 5 pieces each; then per-filter sums ----
             {
+                int info[kPieceRounds];
+                float4 s0[kPieceRounds], s1[kPieceRounds];
+#pragma unroll
+                for (int c = 0; c < kPieceRounds; ++c) info[c] = pinfo[c * kPieceSlots + lane];
 #pragma unroll
                 for (int c = 0; c < kPieceRounds; ++c) {
-                    const int p = c * kPieceSlots + lane;
-                    const int info = pinfo[p];
-                    const float4 w0 = pw4[p], w1 = pw4[kPieces + p];
-                    const float4* s4 = reinterpret_cast<const float4*>(slab + (info & 0xffff));
-                    const float4 s0 = s4[0], s1 = s4[1];
-                    float acc = w0.x * s0.x;
-                    acc = fmaf(w0.y, s0.y, acc);
-                    acc = fmaf(w0.z, s0.z, acc);
-                    acc = fmaf(w0.w, s0.w, acc);
-                    acc = fmaf(w1.x, s1.x, acc);
-                    acc = fmaf(w1.y, s1.y, acc);
-                    acc = fmaf(w1.z, s1.z, acc);
-                    acc = fmaf(w1.w, s1.w, acc);
-                    partial[info >> 16] = acc;
+                    const float4* s4 = reinterpret_cast<const float4*>(slab + (info[c] & 0xffff));
+                    s0[c] = s4[0];
+                    s1[c] = s4[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < kPieceRounds; ++c) {
+                    const float4 w0 = pw0[c], w1 = pw1[c];
+                    float acc = w0.x * s0[c].x;
+                    acc = fmaf(w0.y, s0[c].y, acc);
+                    acc = fmaf(w0.z, s0[c].z, acc);
+                    acc = fmaf(w0.w, s0[c].w, acc);
+                    acc = fmaf(w1.x, s1[c].x, acc);
+                    acc = fmaf(w1.y, s1[c].y, acc);
+                    acc = fmaf(w1.z, s1[c].z, acc);
+                    acc = fmaf(w1.w, s1[c].w, acc);
+                    partial[info[c] >> 16] = acc;
                 }
                 lds_order();
                 STAMP(4);
