@@ -324,6 +324,18 @@ __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh,
     if (second) conv1_row_store(r1, rec + qb * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
 }
 
+// Workgroup-local progress counters in LDS (monotonic).  signal = release add by one wave; wait = acquire poll.  The
+// poll is bounded (~0.2 s): a protocol bug would then show up as a parity failure, not as a hung GPU.
+__device__ __forceinline__ void flag_signal(uint32_t* f) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 #ifdef WW_STAMPS
 __device__ unsigned long long g_cnn_stamps[16];
 #define CSTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
@@ -372,6 +384,9 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         // the consumers wait a third of the time at the band barrier.
         __builtin_amdgcn_s_setprio(3);
     }
+    // progress counters: tiles produced x 4 producer waves, bands consumed x 8 consumer waves, mel planes loaded x 4
+    __shared__ uint32_t prod_done, cons_done, mel_done;
+    if (tid == 0) { prod_done = 0u; cons_done = 0u; mel_done = 0u; }
     for (int i = tid; i < kC2h16Lds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
     __syncthreads();
 
@@ -420,37 +435,44 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         out[clip * 64 + lane] = (red[t_nt * 16 + t_n] + red[(4 + t_nt) * 16 + t_n]) * half_inv_area;
     };
 
-    if (!consumer && steps > 0) load_mel(0);
-    __syncthreads();
-    if (!consumer && steps > 0) {
-        produce(0);
-        if (my_clips > 1) load_mel(1);
-    }
-    __syncthreads();
-
     float pool = 0.f;
 #ifdef WW_STAMPS
     unsigned long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clast = 0;
     CSTAMP(7);
 #endif
-    // Two loops, one per role, with the same number of barriers: the consumers' resident B operands and accumulators
-    // are then not live in the producers' code (a single loop with a role branch makes the allocator keep both sets).
+    // One loop per role (the consumers' resident B operands and accumulators are then not live in the producers' code)
+    // and NO workgroup barrier in the steady state; the roles meet through the three counters:
+    //   a consumer starts band g when tile g is complete                          (prod_done >= 4 (g + 1))
+    //   a producer writes tile g once every consumer has finished band g - 2      (cons_done >= 8 (g - 1), same buffer)
+    //   the four producers advance tile by tile                                   (prod_done >= 4 g): the halo copy
+    //     reads tile g - 1, which a producer running ahead would be overwriting with tile g + 1; the same wait frees
+    //     the mel planes of the previous clip for the next load
+    // so a consumer wave that is done early flows into the next band instead of idling at a barrier while its SIMD
+    // sibling finishes (-4 %).
     if (!consumer) {
+        if (steps > 0) { load_mel(0); flag_signal(&mel_done); }
         for (int g = 0; g < steps; ++g) {
+            const int k = g / (kH / kBand), band = g - k * (kH / kBand);
             CSTAMP(0);
-            if (g + 1 < steps) {
-                produce(g + 1);
-                const int k1 = (g + 1) / (kH / kBand);
-                if ((g + 1) - k1 * (kH / kBand) == 0 && k1 + 1 < my_clips) load_mel(k1 + 1);
-                CSTAMP(3);
-            }
-            __syncthreads();
+            flag_wait(&prod_done, 4u * unsigned(g));
+            if (band == 0) flag_wait(&mel_done, 4u * unsigned(k + 1));
+            if (g >= 2) flag_wait(&cons_done, 8u * unsigned(g - 1));
             CSTAMP(4);
+            produce(g);
+            flag_signal(&prod_done);
+            if (band == 0 && k + 1 < my_clips) {       // planes (k + 1) & 1 were clip k - 1's, whose last tile is complete
+                load_mel(k + 1);
+                flag_signal(&mel_done);
+            }
+            CSTAMP(3);
         }
     } else {
     for (int g = 0; g < steps; ++g) {
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
         CSTAMP(0);
+        flag_wait(&prod_done, 4u * unsigned(g + 1));                   // tile g complete
+        if (POOL && band == 0 && g > 0 && wave == 0) flag_wait(&cons_done, 8u * unsigned(g));   // red[] of clip k - 1 complete
+        CSTAMP(4);
         {
             if (POOL && band == 0 && g > 0 && wave == 0) write_pooled(k - 1);
             const char* ap = act0 + (g & 1) * kH16Act + ((rg * 4) * kRS + pi) * kPos16 + kq * 16;
@@ -536,11 +558,13 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             }
             CSTAMP(2);
         }
-        __syncthreads();
-        CSTAMP(4);
+        flag_signal(&cons_done);
     }
     }
-    if (POOL && consumer && wave == 0 && steps > 0) write_pooled(my_clips - 1);
+    if (POOL && consumer && wave == 0 && steps > 0) {
+        flag_wait(&cons_done, 8u * unsigned(steps));
+        write_pooled(my_clips - 1);
+    }
 #ifdef WW_STAMPS
     if (lane == 0 && blockIdx.x == 7 && (wave == 1 || wave == 9))
         for (int i = 0; i < 8; ++i) atomicAdd(&g_cnn_stamps[i + (wave == 9 ? 8 : 0)], cst[i]);

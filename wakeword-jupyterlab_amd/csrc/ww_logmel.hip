@@ -112,6 +112,14 @@ __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// max(|a|, |b|, m) in one v_max3_f32 with |.| source modifiers (fmaxf semantics: a NaN operand is ignored; m >= 0).
+// Written as fmaxf(fabsf ..) the compiler adds a canonicalising v_max per operand: 43 instructions per frame for 8 samples.
+__device__ __forceinline__ float absmax3(float a, float b, float m) {
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
+
 // Eight 16-byte loads of one frame (samples base + 256*n1 .. +3) through a buffer descriptor whose range is exactly the
 // clip: the hardware returns 0 for every dword outside [0, clip_len) -- the STFT's centre padding, the right zero-pad
 // of short clips and "no next clip" (a zero-record descriptor) cost no compare, select or branch, and the eight loads
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
                 const float4 s = sn[n1];
                 const float4 w = win4[64 * n1 + lane];
                 // every sample sits in 4 frames; samples [512 t, 512 t + 512) = loads n1 4 and 5 of frame t tile the clip once
-                if (n1 == 4 || n1 == 5) peak = fmaxf(peak, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
+                if (n1 == 4 || n1 == 5) peak = absmax3(s.z, s.w, absmax3(s.x, s.y, peak));
                 za[n1] = make_float2(s.x * w.x, s.y * w.y);
                 zb[n1] = make_float2(s.z * w.z, s.w * w.w);
             }
