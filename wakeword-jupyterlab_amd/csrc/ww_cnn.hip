@@ -217,7 +217,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kPos16 = 160;
 constexpr int kH16Row = kRS * kPos16;
 constexpr int kH16Act = kARows * kH16Row;                   // 54,400 B per buffer
-constexpr int kC2h16Lds = 2 * kH16Act + 4 * ((kH + 2) * 36) * 2 + 8 * 16 * 4;
+constexpr int kZeroRowsHalfs = (kH + 2) * 36 + 3 * 36;            // three zero rows whose lo twin (+ one plane) is zero too
+constexpr int kC2h16Lds = 2 * kH16Act + (4 * ((kH + 2) * 36) + kZeroRowsHalfs) * 2 + 8 * 16 * 4;
 
 // conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
 //   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
@@ -230,30 +231,37 @@ constexpr int kMelHPlane = (kH + 2) * kMelHRS;           // halfs per plane
 struct Conv1Row {
     half8 ph, pl;       // patch operand B[k = 8h + j][x], hi and lo halves
     f32x16 acc;
-    bool ok;            // row inside the image (uniform)
 };
 
-__device__ __forceinline__ void conv1_row_gather(Conv1Row& r, const _Float16* __restrict__ mh, const _Float16* __restrict__ ml,
-                                                 int y, int x, int h) {
-    r.ok = y >= 0 && y < kH;
-    const int yy = r.ok ? y : 0;
-    const _Float16 one = static_cast<_Float16>(1.0f), zero = static_cast<_Float16>(0.0f);
+// Patch operand of a row: lane (x, h) needs B[k = 8h + j][x], j = 0..7 -- taps 0..7 for the lower half-wave; tap 8, the
+// bias tap (1.0) and six zeros for the upper one.  Column 34 of every row of the hi plane holds 1.0 and column 35 (and
+// both columns of the lo plane) 0, so the upper half-wave differs from the lower one only in its ADDRESSES: eight
+// per-lane offsets, computed once, replace 32 selects per row.  (ds_read_u16_d16 pairs would also save the packing, but
+// with SRAM ECC on a d16 load clears the other half of its register.)
+struct GatherLanes { int o[8]; };      // offsets in halfs relative to the first plane row of the patch, column 0
+
+__device__ __forceinline__ GatherLanes gather_lanes(int x, int h) {
+    GatherLanes g;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                      // lower half-wave: taps 0..7; upper: tap 8, the bias tap (1.0), zeros
-        const int o0 = (yy + j / 3) * kMelHRS + x + j % 3;             // tile coords: row y+dy-1 -> y+dy, col x+dx-1 -> x+dx
-        const _Float16 vh0 = mh[o0], vl0 = ml[o0];
-        if (j == 0) {
-            const int o1 = (yy + 2) * kMelHRS + x + 2;                 // tap 8 (dy = 2, dx = 2)
-            const _Float16 vh1 = mh[o1], vl1 = ml[o1];
-            r.ph[j] = h ? vh1 : vh0;
-            r.pl[j] = h ? vl1 : vl0;
-        } else if (j == 1) {
-            r.ph[j] = h ? one : vh0;
-            r.pl[j] = h ? zero : vl0;
-        } else {
-            r.ph[j] = h ? zero : vh0;
-            r.pl[j] = h ? zero : vl0;
-        }
+    for (int j = 0; j < 8; ++j) {
+        const int lower = (j / 3) * kMelHRS + j % 3 + x;                             // tile coords: row y+dy, col x+dx
+        const int upper = j == 0 ? 2 * kMelHRS + 2 + x : (j == 1 ? 34 : 35);
+        g.o[j] = h ? upper : lower;
+    }
+    return g;
+}
+
+// Rows outside the image (conv2's zero padding) and columns beyond `width` must come out as exact zeros: their lanes
+// read an all-zero patch -- bias tap included -- from `zrow` (three zero rows whose lo twin is zero too): ONE address
+// select per row instead of a select per output value.
+__device__ __forceinline__ void conv1_row_gather(Conv1Row& r, const _Float16* __restrict__ mh, const _Float16* __restrict__ zrow,
+                                                 const GatherLanes& gl, int y, bool col_ok) {
+    const bool live = y >= 0 && y < kH && col_ok;
+    const _Float16* __restrict__ row = live ? mh + y * kMelHRS : zrow;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r.ph[j] = row[gl.o[j]];
+        r.pl[j] = row[gl.o[j] + kMelHPlane];             // the lo plane follows the hi plane
     }
 }
 
@@ -280,20 +288,14 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 
 // D: lane&31 = column x; the weight rows are permuted on the host so that register j holds channel 16*h + j:
 // 2*relu, hi/lo split, and the lane's 16 contiguous channels go out as two 16-byte stores per half.
-__device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restrict__ rec, bool keep, bool full) {
+__device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restrict__ rec) {
 #pragma unroll
     for (int g8 = 0; g8 < 2; ++g8) {
-        float t[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            t[e] = relu2(r.acc[8 * g8 + e]);                           // 2*relu: the factor is folded into conv2's descale
-            if (!full) t[e] = keep ? t[e] : 0.f;
-        }
         u32x4 vh, vl;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            uint32_t hh, ll;
-            split2(t[2 * d], t[2 * d + 1], hh, ll);
+            uint32_t hh, ll;       // 2*relu: the factor is folded into conv2's descale
+            split2(relu2(r.acc[8 * g8 + 2 * d]), relu2(r.acc[8 * g8 + 2 * d + 1]), hh, ll);
             vh[d] = hh;
             vl[d] = ll;
         }
@@ -302,26 +304,21 @@ __device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restr
     }
 }
 
-// conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
-//   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
-// The log-mel tile is kept as two f16 planes (hi, lo) so the patch operand needs no conversions.
-// A producer runs the rows qa and (if >= 0) qb of the band's tile side by side.
-__device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const _Float16* __restrict__ ml,
-                                                char* __restrict__ act, half8 a1h, half8 a1l, int y0, int width,
-                                                int qa, int qb, int lane) {
+// A producer runs tile rows qa and (if SECOND) qa + 4 of the band side by side.  mh: the clip's hi plane.
+template <int POS, bool SECOND>
+__device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const _Float16* __restrict__ zrow,
+                                                const GatherLanes& gl, char* __restrict__ act, half8 a1h, half8 a1l, int y0,
+                                                int width, int qa, int lane) {
     const int x = lane & 31, h = lane >> 5;
-    const bool full = width == kW;                       // uniform: skips the per-value column mask
-    const bool second = qb >= 0;                         // uniform
-    Conv1Row r0, r1;
-    conv1_row_gather(r0, mh, ml, y0 - 1 + qa, x, h);
-    if (second) conv1_row_gather(r1, mh, ml, y0 - 1 + qb, x, h);
-    conv1_row_mfma(r0, a1h, a1l);
-    if (second) conv1_row_mfma(r1, a1h, a1l);
-    char* rec = act + (x + 1) * kPos16 + h * 32;                       // this lane's 16 channels 16h..16h+15
     const bool col_ok = x < width;
-    // rows outside the image are conv2's zero padding: `keep` false zeroes them (never `full` for such a row)
-    conv1_row_store(r0, rec + qa * kRS * kPos16, col_ok && r0.ok, full && r0.ok);
-    if (second) conv1_row_store(r1, rec + qb * kRS * kPos16, col_ok && r1.ok, full && r1.ok);
+    Conv1Row r0, r1;
+    conv1_row_gather(r0, mh, zrow, gl, y0 - 1 + qa, col_ok);
+    if (SECOND) conv1_row_gather(r1, mh, zrow, gl, y0 - 1 + qa + 4, col_ok);
+    conv1_row_mfma(r0, a1h, a1l);
+    if (SECOND) conv1_row_mfma(r1, a1h, a1l);
+    char* rec = act + (x + 1) * POS + h * 32;                          // this lane's 16 channels 16h..16h+15
+    conv1_row_store(r0, rec + qa * kRS * POS);
+    if (SECOND) conv1_row_store(r1, rec + (qa + 4) * kRS * POS);
 }
 
 // Workgroup-local progress counters in LDS (monotonic).  signal = release add by one wave; wait = acquire poll.  The
@@ -355,7 +352,8 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* act0 = ldsb;
     _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + 2 * kH16Act);       // 2 clips x (hi plane, lo plane) of [82][36] f16
-    float* red = reinterpret_cast<float*>(melh0 + 4 * kMelHPlane);           // [8 consumer waves][16]
+    const _Float16* zrow = melh0 + 4 * kMelHPlane;                           // zero patch rows (never written)
+    float* red = reinterpret_cast<float*>(melh0 + 4 * kMelHPlane + kZeroRowsHalfs);   // [8 consumer waves][16]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,9 +374,12 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         descale = 0.5f * hs[0];                  // conv1 activations are stored as 2*relu(.)
     }
     half8 a1h = {}, a1l = {};
+    const GatherLanes glanes = gather_lanes(lane & 31, lane >> 5);
     if (!consumer) {
-        a1h = __builtin_bit_cast(half8, w1H[lane]);
-        a1l = __builtin_bit_cast(half8, w1H[64 + lane]);
+        u32x4 w1h_r = w1H[lane], w1l_r = w1H[64 + lane];
+        asm volatile("" : "+v"(w1h_r), "+v"(w1l_r));    // opaque: otherwise the loads are rematerialised inside the band loop
+        a1h = __builtin_bit_cast(half8, w1h_r);
+        a1l = __builtin_bit_cast(half8, w1l_r);
         // The producers are VALU streams sharing each SIMD's issue port with two MFMA streams (an MFMA holds the port
         // for 8 of its 16 cycles); issue is arbitrated by priority, then age.  Without this the producers starve and
         // the consumers wait a third of the time at the band barrier.
@@ -387,7 +388,12 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     // progress counters: tiles produced x 4 producer waves, bands consumed x 8 consumer waves, mel planes loaded x 4
     __shared__ uint32_t prod_done, cons_done, mel_done;
     if (tid == 0) { prod_done = 0u; cons_done = 0u; mel_done = 0u; }
-    for (int i = tid; i < kC2h16Lds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
+    // zero fill; column 34 of every row of the two hi planes is the constant 1.0 (f16 0x3C00) of the bias tap
+    for (int i = tid; i < kC2h16Lds / 4; i += 768) {
+        const int w = i - 2 * kH16Act / 4;               // dword index inside the four planes (hi, lo, hi, lo)
+        const bool one = w >= 0 && w < 4 * (kMelHPlane / 2) && ((w / (kMelHPlane / 2)) & 1) == 0 && (w % (kMelHRS / 2)) == 17;
+        reinterpret_cast<uint32_t*>(ldsb)[i] = one ? 0x00003C00u : 0u;
+    }
     __syncthreads();
 
     const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
@@ -412,21 +418,27 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     // eight rows are computed, two per producer.
     auto produce = [&](int g) {
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
-        const _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
+        const _Float16* plane = melh0 + (k & 1) * 2 * kMelHPlane;      // hi plane of the clip (lo plane behind it)
         char* tile = act0 + (g & 1) * kH16Act;
         const int pw = wave - 8;
-        conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, band * kBand, width, 2 + pw, 6 + pw, lane);
         if (band == 0) {
-            if (pw < 2) conv1_rows_mfma(ph, ph + kMelHPlane, tile, a1h, a1l, 0, width, pw, -1, lane);
+            conv1_rows_mfma<kPos16, true>(plane, zrow, glanes, tile, a1h, a1l, 0, width, 2 + pw, lane);
+            if (pw < 2) conv1_rows_mfma<kPos16, false>(plane, zrow, glanes, tile, a1h, a1l, 0, width, pw, lane);
             return;
         }
+        // halo rows: read first, written last -- the LDS round trip hides under the conv1 work
         const char* prev = act0 + ((g & 1) ^ 1) * kH16Act + 8 * kH16Row;
+        u32x4 halo[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int c = ptid + 256 * i;                              // chunk: position c >> 3 (2 rows x 34), 16-byte part c & 7
-            if (c < 2 * kRS * 8)
-                *reinterpret_cast<u32x4*>(tile + (c >> 3) * kPos16 + (c & 7) * 16) =
-                    *reinterpret_cast<const u32x4*>(prev + (c >> 3) * kPos16 + (c & 7) * 16);
+            if (c < 2 * kRS * 8) halo[i] = *reinterpret_cast<const u32x4*>(prev + (c >> 3) * kPos16 + (c & 7) * 16);
+        }
+        conv1_rows_mfma<kPos16, true>(plane, zrow, glanes, tile, a1h, a1l, band * kBand, width, 2 + pw, lane);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = ptid + 256 * i;
+            if (c < 2 * kRS * 8) *reinterpret_cast<u32x4*>(tile + (c >> 3) * kPos16 + (c & 7) * 16) = halo[i];
         }
     };
     auto write_pooled = [&](int k) {     // wave 0: pooled[clip][co], co = lane: sum the two row groups
