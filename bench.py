@@ -18,6 +18,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   cpu_baseline  the CPU oracle (numpy log-mel per clip + torch CPU Conv2d/LSTM/Linear) timed on this
                 host on a bounded sample of the same clips (rank 0, N = 1 only)
   parity        max |err| of the measured path against that oracle on the sample
+  augmentation  augment_audio on the GPU: clips/s for plans drawn like the reference, error vs the oracle
   streaming     BASELINE configs[4] (256 microphones, 10 ms hop, hipGraph replay per hop): p50/p99 hop latency, hops/s
                 (rank 0, N = 1 only; measured after the timed region)
 """
@@ -282,6 +283,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import bench_streaming
             out["streaming"] = bench_streaming.measure(mics=256, hop=160, hops=1000, device=dev.index)
+            # AudioProcessor.augment_audio on the GPU (training-side stage that feeds K1)
+            import bench_augment
+            out["augmentation"] = bench_augment.measure(batch=B, steps=5, check=4, device=dev.index)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -18,14 +18,11 @@ import wakeword_jupyterlab_amd as pkg  # noqa: E402
 from wakeword_jupyterlab_amd import ops  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--check", type=int, default=8, help="clips compared with oracle/augment_oracle.py")
-    args = ap.parse_args()
+def measure(batch=4096, steps=10, check=8, device=0):
+    """Run the augmentation benchmark and return its result dict (bench.py embeds it in its JSON line at N=1)."""
+    args = argparse.Namespace(batch=batch, steps=steps, check=check)
     from oracle import augment_oracle as ao
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", device)
     B = args.batch
     x = pkg.synth.make_clips_tiled(0, B, unique=64)
     x = x / np.abs(x).max(axis=1, keepdims=True)
@@ -64,7 +61,16 @@ def main():
            "oracle_clips_per_s_1_thread": 1.0 / cpu_s, "checked_clips": args.check,
            "max_abs_err_over_peak": float((err.max(axis=1) / np.abs(want).max(axis=1)).max()),
            "rms_err_over_rms": float((np.sqrt((err ** 2).mean(axis=1)) / np.sqrt((want.astype(np.float64) ** 2).mean(axis=1))).max())}
-    print(json.dumps(res))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--check", type=int, default=8, help="clips compared with oracle/augment_oracle.py")
+    args = ap.parse_args()
+    print(json.dumps(measure(args.batch, args.steps, args.check)))
 
 
 if __name__ == "__main__":
