@@ -224,7 +224,7 @@ def test_full_batch_properties_4096(ops, dev):
 
 
 @pytest.mark.parametrize("arch", ["simple", "full"])
-@pytest.mark.parametrize("n", [255, 257, 517, 1030])
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 511, 517, 1030, 2049])
 def test_ragged_batch_sizes_agree_with_small_batches(ops, dev, arch, n):
     # persistent kernels loop over clips with grid = resident workgroups: batch sizes around the CU count (256) and
     # not divisible by anything must give, clip for clip, exactly what small batches give
