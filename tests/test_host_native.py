@@ -169,3 +169,21 @@ def test_argument_checks_come_before_device_checks():
     assert nat.lib.ww_logmel_f32(buf.ctypes.data + 4, 2, 16000, 16000, 1, buf.ctypes.data, None) == nat.WW_EINVAL
     assert nat.lib.ww_cnn_pool_f32(buf.ctypes.data, 1, 40, buf.ctypes.data, 2, None, buf.ctypes.data, None) == nat.WW_EUNSUPPORTED
     assert nat.lib.ww_lstm_fc_f32(buf.ctypes.data, 1, buf.ctypes.data, 7, buf.ctypes.data, None) == nat.WW_EINVAL
+
+
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    """include/wakeword_amd.h compiles as strict C99 and a C program drives the library (tests/c/abi_host_check.c)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "wakeword-jupyterlab_amd")
+    exe = os.path.join(tmp_path, "abi_host_check")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "abi_host_check.c"), "-o", exe, "-L", libdir, "-l:libwakeword_amd.so", "-lm",
+                    "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.dirname(torch.__file__) + "/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe] + (["gpu"] if HAS_GPU else []), capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "abi_host_check OK" in r.stdout, r.stderr
