@@ -11,7 +11,7 @@
 //   f16x3 (default)  cnn2h16_kernel<POOL> [+ cnn3h_kernel]: every fp32 operand as two f16 halves, three
 //                    v_mfma_f32_16x16x32_f16 per product block, fp32 accumulate (~2^-21 relative).  12-wave workgroup:
 //                    8 consumer waves (2 per SIMD) + 4 producer waves that run conv1 -- itself an MFMA -- one band ahead
-//                    into a double-buffered LDS tile.
+//                    into a double-buffered LDS tile; the roles meet through progress counters in LDS, not barriers.
 //   f32              cnn2_kernel<POOL> [+ cnn3_kernel]: v_mfma_f32_32x32x2_f32, exact fp32 (bit-for-bit an fmaf chain);
 //                    conv1 on the VALU per band.
 //
@@ -345,7 +345,6 @@ __device__ unsigned long long g_cnn_stamps[16];
 // [n][80 rows][32 columns][64 ci hi | 64 ci lo] (256 bytes per position, zero beyond `width`).
 template <bool POOL>
 __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict__ mel, int n, int width,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const u32x4* __restrict__ w1H,
                                                          const u32x4* __restrict__ wH, const float* __restrict__ hs,
                                                          const float* __restrict__ b2, float* __restrict__ out) {
@@ -819,15 +818,13 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
         const u32x4* w1h = reinterpret_cast<const u32x4*>(packed + L.conv1_h);
         const u32x4* w2h = reinterpret_cast<const u32x4*>(packed + L.conv2_h16);
         if (n_conv == 2) {
-            hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width,
-                               packed + L.conv1_w, packed + L.conv1_b, w1h, w2h, packed + L.conv2_hs, packed + L.conv2_b,
-                               pooled);
+            hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width, w1h, w2h,
+                               packed + L.conv2_hs, packed + L.conv2_b, pooled);
             WW_HIP(hipGetLastError());
             return WW_OK;
         }
-        hipLaunchKernelGGL(cnn2h16_kernel<false>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width,
-                           packed + L.conv1_w, packed + L.conv1_b, w1h, w2h, packed + L.conv2_hs, packed + L.conv2_b,
-                           static_cast<float*>(scratch));
+        hipLaunchKernelGGL(cnn2h16_kernel<false>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width, w1h, w2h,
+                           packed + L.conv2_hs, packed + L.conv2_b, static_cast<float*>(scratch));
         WW_HIP(hipGetLastError());
         hipLaunchKernelGGL(cnn3h_kernel, dim3(grid1), dim3(512), kC3hLds, stream, static_cast<const _Float16*>(scratch),
                            int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_h), packed + L.conv3_hs,

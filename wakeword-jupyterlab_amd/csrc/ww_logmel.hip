@@ -24,34 +24,22 @@ constexpr int kThreads = kWavesPerBlock * 64;
 // wave slab: 1024 complex = 2048 floats (+4 keeps 16-byte alignment and staggers the slabs over the banks)
 constexpr int kSlab = 2048 + 4;
 constexpr int kMelStride = kFrames + 1;
-// LDS map (floats): slabs | mel | reduce scratch | sparse-mel tables | twiddle tables | window.
+// LDS map (floats): slabs | mel | reduce scratch | piece index | filter index | pass-2 twiddles | pair twiddles.
+// Window, pass-1 twiddles and piece weights are read through L1 from the global table (25 KB less LDS per workgroup:
+// three workgroups per CU instead of two).
 // The per-wave piece sums live in the upper half of the wave's slab (the power spectrum only needs floats 0..1024).
 constexpr int kPartialInSlab = 1032;
 static_assert(kPartialInSlab + kPieces <= kSlab, "piece sums must fit behind the power spectrum");
 constexpr int kOffMel = kWavesPerBlock * kSlab;
 constexpr int kOffRed = kOffMel + kMels * kMelStride;
-constexpr int kOffPw = kOffRed + 16;                    // [2][kPieces][4] (lean variant: unused, kept for the offsets)
-#ifndef WW_K1_FAT_LDS
-constexpr int kOffPinfo = kOffPw;                       // piece weights stay in global memory
-#else
-constexpr int kOffPinfo = kOffPw + 2 * kPieces * 4;     // [kPieces] ints
-#endif
+constexpr int kOffPinfo = kOffRed + 16;                 // [kPieces] ints
 constexpr int kOffFp0 = kOffPinfo + kPieces;            // [80] ints
 constexpr int kOffFcnt = kOffFp0 + kMels;               // [80] ints
 constexpr int kOffTw2 = kOffFcnt + kMels;               // [7][16] float2
 constexpr int kOffTwp = kOffTw2 + 7 * 16 * 2;           // [512] float2
-constexpr int kOffTw1 = kOffTwp + 512 * 2;              // [7][128] float2
-constexpr int kOffWin = kOffTw1 + 7 * 128 * 2;          // [2048]
-#ifndef WW_K1_FAT_LDS
-// lean variant: window, pass-1 twiddles and piece weights are read through L1 from the global table instead
-// (25 KB less LDS per workgroup: 3 workgroups per CU instead of 2)
-constexpr int kLdsFloats = kOffTw1;
+constexpr int kLdsFloats = kOffTwp + 512 * 2;
 constexpr int kBlocksPerCu = 3;
-#else
-constexpr int kLdsFloats = kOffWin + kNfft;
-constexpr int kBlocksPerCu = 2;
-#endif
-static_assert(kOffPw % 4 == 0 && kOffTw2 % 4 == 0 && kOffTwp % 2 == 0 && kOffTw1 % 4 == 0 && kOffWin % 4 == 0, "LDS table alignment");
+static_assert(kOffPinfo % 4 == 0 && kOffTw2 % 4 == 0 && kOffTwp % 2 == 0, "LDS table alignment");
 
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -160,11 +148,7 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mel = lds + kOffMel;                                 // [80][33]
     float* red = lds + kOffRed;                                 // [16]
-#ifndef WW_K1_FAT_LDS
     const float4* pw4 = reinterpret_cast<const float4*>(&tb->piece_w[0][0][0]);
-#else
-    const float4* pw4 = reinterpret_cast<const float4*>(lds + kOffPw);   // [2][kPieces]
-#endif
     const int* pinfo = reinterpret_cast<const int*>(lds + kOffPinfo);
     const int* fp0 = reinterpret_cast<const int*>(lds + kOffFp0);
     const int* fcnt = reinterpret_cast<const int*>(lds + kOffFcnt);
@@ -179,18 +163,10 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
     float2* slab2 = reinterpret_cast<float2*>(slab);
     float4* slab4 = reinterpret_cast<float4*>(slab);
     float* partial = slab + kPartialInSlab;                     // this wave's piece sums, filter-major
-#ifndef WW_K1_FAT_LDS
     const float4* tw1_4 = reinterpret_cast<const float4*>(&tb->tw1[0][0]);
     const float4* win4 = reinterpret_cast<const float4*>(&tb->window[0]);
-#else
-    const float4* tw1_4 = reinterpret_cast<const float4*>(lds + kOffTw1);   // [7][64] float4 = twiddles of n' = 2l, 2l+1
-    const float4* win4 = reinterpret_cast<const float4*>(lds + kOffWin);
-#endif
 
     // ---- all tables into LDS once per workgroup (conflict-free, lane-contiguous reads) ----
-#ifdef WW_K1_FAT_LDS
-    for (int i = tid; i < 2 * kPieces * 4; i += kThreads) lds[kOffPw + i] = (&tb->piece_w[0][0][0])[i];
-#endif
     for (int i = tid; i < kPieces; i += kThreads) reinterpret_cast<int*>(lds)[kOffPinfo + i] = tb->piece_info[i];
     if (tid < kMels) {
         reinterpret_cast<int*>(lds)[kOffFp0 + tid] = tb->filt_p0[tid];
@@ -198,10 +174,6 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
     }
     for (int i = tid; i < 7 * 16 * 2; i += kThreads) lds[kOffTw2 + i] = (&tb->tw2[0][0].x)[i];
     for (int i = tid; i < 512 * 2; i += kThreads) lds[kOffTwp + i] = (&tb->twp[0].x)[i];
-#ifdef WW_K1_FAT_LDS
-    for (int i = tid; i < 7 * 128 * 2; i += kThreads) lds[kOffTw1 + i] = (&tb->tw1[0][0].x)[i];
-    for (int i = tid; i < kNfft; i += kThreads) lds[kOffWin + i] = tb->window[i];
-#endif
     const int ring_pos = RING ? *ring_pos_p : 0;
     __syncthreads();
     // this lane's filters in the per-frame combine: f = lane and f = lane + 64 (< 80)
