@@ -71,6 +71,7 @@ __device__ __forceinline__ void lstm_layer(const float* __restrict__ xs, int xst
 #pragma unroll
             for (int t = 0; t < 6; ++t) bw[kg % D][t] = b_p[(int64_t(kg + D) * kGateCols + 16 * t) * 4];
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the weight loads D groups ahead (the scheduler sinks them to their use)
         const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -79,6 +80,7 @@ __device__ __forceinline__ void lstm_layer(const float* __restrict__ xs, int xst
                 const float bv = s == 0 ? bc[t].x : s == 1 ? bc[t].y : s == 2 ? bc[t].z : bc[t].w;
                 acc[t >> 1][t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[t >> 1][t & 1], 0, 0, 0);
             }
+        __builtin_amdgcn_sched_barrier(0);
     }
     // D: lane&15 = hidden unit within the half, register j <-> clip 4*(lane>>4) + j
 #pragma unroll
