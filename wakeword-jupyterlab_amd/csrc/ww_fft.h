@@ -71,13 +71,18 @@ __device__ __forceinline__ void wave_fft1024(float2 (&za)[8], float2 (&zb)[8], f
     float2* slab2 = reinterpret_cast<float2*>(slab);
     const float4* tw1_4 = reinterpret_cast<const float4*>(&tb->tw1[0][0]);   // [7][64]: twiddles of n' = 2 lane, 2 lane + 1
     const float4* tw2_4 = reinterpret_cast<const float4*>(&tb->tw2[0][0]);   // [7][8]
-    // pass 1: radix 8 over n1 (stride 128), twiddle W_1024^{n' k1}
+    // pass 1: radix 8 over n1 (stride 128), twiddle W_1024^{n' k1}.  Twiddles are fetched as a group ahead of the
+    // butterflies (written at their use each load is issued right there: one L1 round trip per twiddle).
+    float4 t1[7];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) t1[k1 - 1] = tw1_4[(k1 - 1) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
     dft8(za);
     dft8(zb);
     slab4[lane] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1) {
-        const float4 t = tw1_4[(k1 - 1) * 64 + lane];
+        const float4 t = t1[k1 - 1];
         const float2 a = cmul(za[k1], make_float2(t.x, t.y));
         const float2 b = cmul(zb[k1], make_float2(t.z, t.w));
         slab4[k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)))] = make_float4(a.x, a.y, b.x, b.y);
@@ -95,7 +100,11 @@ __device__ __forceinline__ void wave_fft1024(float2 (&za)[8], float2 (&zb)[8], f
             za[n2] = make_float2(v.x, v.y);
             zb[n2] = make_float2(v.z, v.w);
         }
+        float4 t2[7];
+#pragma unroll
+        for (int k2 = 1; k2 < 8; ++k2) t2[k2 - 1] = tw2_4[(k2 - 1) * 8 + jr];
         lds_order();
+        __builtin_amdgcn_sched_barrier(0);
         dft8(za);
         dft8(zb);
         float4* x2w[4];
@@ -105,7 +114,7 @@ __device__ __forceinline__ void wave_fft1024(float2 (&za)[8], float2 (&zb)[8], f
         for (int k2 = 0; k2 < 8; ++k2) {
             float2 a = za[k2], b = zb[k2];
             if (k2 > 0) {
-                const float4 t = tw2_4[(k2 - 1) * 8 + jr];
+                const float4 t = t2[k2 - 1];
                 a = cmul(a, make_float2(t.x, t.y));
                 b = cmul(b, make_float2(t.z, t.w));
             }
