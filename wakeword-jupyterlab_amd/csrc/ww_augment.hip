@@ -14,7 +14,7 @@
 //   istft_kernel      Hermitian spectrum -> conj(Z) -> the same forward FFT -> frame; window; overlap-add in an LDS
 //                     buffer that holds the whole stretched clip, in frame order (one barrier per frame, the adds are
 //                     cheap); window sum-square normalisation, centre trim, crop / zero-pad
-//   resample_kernel   windowed-sinc interpolation at t = i / ratio (resampy 'kaiser_best' table in LDS): the stand-in
+//   resample_kernel   windowed-sinc interpolation at t = i / ratio (resampy 'kaiser_best' table in LDS, float32 MACs): the stand-in
 //                     for librosa's soxr_hq (absent third-party library; parity unpinned)
 //   noise_kernel      + sigma * normal(seed, i), the build's counter-based generator (splitmix64 -> Box-Muller)
 // Clips whose plan switches a transform off skip its kernels (their blocks copy the data through).
@@ -246,35 +246,38 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
     const float* y = Y + int64_t(clip) * kAugYStride;
     const double inv = 1.0 / ratio;
     for (int t = tid; t < kClip; t += 1024) {
-        double acc = 0.0;
+        // positions and table fractions in float64 (t / ratio needs ~15 integer + 9 fraction bits); the ~270 products per
+        // output are float32 FMAs in two independent chains
+        float accl = 0.f, accr = 0.f;
         const double time_register = double(t) * inv;
         const int n = int(time_register);
         if (t < n_res && n < n_orig) {
             double frac = scale * (time_register - double(n));
             double index_frac = frac * kKbTable;
             int offset = int(index_frac);
-            double eta = index_frac - double(offset);
+            float eta = float(index_frac - double(offset));
             int i_max = (kKbLen - offset) / index_step;
             i_max = i_max < n + 1 ? i_max : n + 1;
             for (int i = 0; i < i_max; ++i) {
                 const int idx = offset + i * index_step;
-                const double w0 = double(tab[idx]), w1 = double(tab[idx + 1]);
-                acc += (w0 + eta * (w1 - w0)) * double(y[n - i]);
+                const float w0 = tab[idx], w1 = tab[idx + 1];
+                accl = fmaf(fmaf(eta, w1 - w0, w0), y[n - i], accl);
             }
             frac = scale - frac;
             index_frac = frac * kKbTable;
             offset = int(index_frac);
-            eta = index_frac - double(offset);
+            eta = float(index_frac - double(offset));
             int k_max = (kKbLen - offset) / index_step;
             k_max = k_max < n_orig - n - 1 ? k_max : n_orig - n - 1;
             for (int k = 0; k < k_max; ++k) {
                 const int idx = offset + k * index_step;
-                const double w0 = double(tab[idx]), w1 = double(tab[idx + 1]);
-                acc += (w0 + eta * (w1 - w0)) * double(y[n + k + 1]);
+                const float w0 = tab[idx], w1 = tab[idx + 1];
+                accr = fmaf(fmaf(eta, w1 - w0, w0), y[n + k + 1], accr);
             }
-            if (ratio < 1.0) acc *= ratio;
         }
-        o[t] = float(acc);
+        float acc = accl + accr;
+        if (ratio < 1.0) acc *= float(ratio);
+        o[t] = acc;
     }
 }
 
