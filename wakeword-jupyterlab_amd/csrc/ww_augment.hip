@@ -11,9 +11,9 @@
 //   pv_kernel         phase vocoder: thread = bin, sequential over the output steps; librosa's arithmetic types are
 //                     kept (float32 magnitudes and phase accumulator, float64 phase advance) so that the accumulator
 //                     rounds the same way
-//   istft_kernel      Hermitian spectrum -> conj(Z) -> the same forward FFT -> frame; window; overlap-add in an LDS
-//                     buffer that holds the whole stretched clip, in frame order (one barrier per frame, the adds are
-//                     cheap); window sum-square normalisation, centre trim, crop / zero-pad
+//   istft_kernel      Hermitian spectrum -> conj(Z) -> the same forward FFT -> frame, four frames per round into a ring
+//                     of eight LDS slabs; the hop segments a round completes are summed straight from the slabs in
+//                     frame order with the window and its sum-square, centre-trimmed, cropped / zero-padded
 //   resample_kernel   windowed-sinc interpolation at t = i / ratio (resampy 'kaiser_best' table in LDS, float32 MACs): the stand-in
 //                     for librosa's soxr_hq (absent third-party library; parity unpinned)
 //   noise_kernel      + sigma * normal(seed, i), the build's counter-based generator (splitmix64 -> Box-Muller)
@@ -27,7 +27,6 @@ namespace ww {
 
 constexpr int kAugFrames = kFrames;                 // STFT frames of a 16000-sample clip (1 + 16000/512 = 32)
 constexpr int kAugMaxOut = 46;                      // phase-vocoder output steps: ceil(32 / rate), rate >= 32/46
-constexpr int kAugMaxLen = kNfft + kHop * (kAugMaxOut - 1);   // 25,088 samples of overlap-add buffer
 constexpr int kAugYStride = 25600;                  // stretched-clip scratch row
 constexpr int kSpec = kBins;                        // 1025 complex bins per spectrum row
 
@@ -133,14 +132,17 @@ __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, c
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int kIstftLds = (kAugMaxLen + 4 * fft::kSlabFloats) * int(sizeof(float));     // 133,184 B
+constexpr int kIstftSlabs = 8;                                   // two rounds of four frames stay resident
+constexpr int kIstftLds = kIstftSlabs * fft::kSlabFloats * int(sizeof(float));          // 65,664 B: two workgroups per CU
 
 // dst[i], i < dst_len, = y[i + crop] (0 past the stretched length); clips with the stage off copy `passthru` instead.
+// Four frames per round (one per wave) into a ring of eight slabs.  A sample of the padded signal in hop segment s is
+// covered by frames s-3..s, so after round r the segments 4r..4r+3 are complete: they are summed straight from the
+// slabs in frame order (librosa's order), normalised and stored -- no overlap-add buffer, two barriers per round.
 __global__ __launch_bounds__(256) void istft_kernel(const float2* __restrict__ S, const AugDev* __restrict__ plan, int which,
                                                     const LogmelTables* __restrict__ tb, const float* __restrict__ passthru,
                                                     float* __restrict__ dst, int64_t dst_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ola = lds;                                            // [kAugMaxLen]
     const int clip = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n_out = which == 0 ? plan[clip].p_out : plan[clip].s_out;
@@ -155,15 +157,12 @@ __global__ __launch_bounds__(256) void istft_kernel(const float2* __restrict__ S
     const int dst_len = which == 0 ? length : kClip;
     int n_frames = (length + kNfft + kHop - 1) / kHop;           // ceil((length + n_fft) / hop)
     n_frames = n_frames < n_out ? n_frames : n_out;
-    float* slab = lds + kAugMaxLen + wave * fft::kSlabFloats;
-    const float2* slab2 = reinterpret_cast<const float2*>(slab);
-    for (int i = tid; i < kAugMaxLen; i += 256) ola[i] = 0.f;
-    __syncthreads();
     const float2* Sc = S + int64_t(clip) * kAugMaxOut * kSpec;
-    for (int r0 = 0; r0 < n_frames; r0 += 4) {
-        const int frame = r0 + wave;
-        const bool live = frame < n_frames;
-        if (live) {
+    const int rounds = (n_frames + 3) / 4 + 1;                   // + a flush round for the tails of the last frames
+    for (int r = 0; r < rounds; ++r) {
+        const int frame = 4 * r + wave;
+        if (frame < n_frames) {
+            float* slab = lds + (frame % kIstftSlabs) * fft::kSlabFloats;
             const float2* X = Sc + int64_t(frame) * kSpec;
             float2 za[8], zb[8];
 #pragma unroll
@@ -183,42 +182,36 @@ __global__ __launch_bounds__(256) void istft_kernel(const float2* __restrict__ S
                 }
             fft::wave_fft1024(za, zb, slab, tb, lane);          // F = FFT(conj Z); z[n] = conj(F[n]) / 1024
         }
-        // overlap-add in frame order: wave s adds in sub-step s
-        for (int s = 0; s < 4; ++s) {
-            if (wave == s && live) {
-                float2* o2 = reinterpret_cast<float2*>(ola + frame * kHop);
-                const float2* w2 = reinterpret_cast<const float2*>(&tb->window[0]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int n = lane + 64 * i;
-                    const float2 f = slab2[fft::zpos(n)];
-                    const float2 w = w2[n];
-                    float2 acc = o2[n];
-                    acc.x += w.x * (f.x * (1.0f / 1024.0f));
-                    acc.y += w.y * (-f.y * (1.0f / 1024.0f));
-                    o2[n] = acc;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // window sum-square at sample n of the padded signal, float32 in frame order as librosa accumulates it
-    for (int i = tid; i < dst_len; i += 256) {
-        const int src = i + crop;
-        float v = 0.f;
-        if (src < length) {
-            const int n = src + kNfft / 2;
-            v = n < kAugMaxLen ? ola[n] : 0.f;
-            int f0 = (n - kNfft + kHop) / kHop;                  // first frame that covers n
+        __syncthreads();                                         // frames <= 4r + 3 are in their slabs
+        // segments 4r .. 4r+3 of the padded signal: 1024 sample PAIRS (2p, 2p+1), four per thread
+        for (int pp = tid; pp < 4 * kHop / 2; pp += 256) {
+            const int n = 4 * r * kHop + 2 * pp;                 // even sample of the pair
+            const int seg = n / kHop;
+            int f0 = seg - 3;
             f0 = f0 < 0 ? 0 : f0;
-            int f1 = n / kHop;
-            f1 = f1 < n_frames - 1 ? f1 : n_frames - 1;
-            float ws = 0.f;
-            for (int f = f0; f <= f1; ++f) { const float w = tb->window[n - f * kHop]; ws += w * w; }
-            if (ws > 1.17549435e-38f) v = v / ws;
+            const int f1 = seg < n_frames - 1 ? seg : n_frames - 1;
+            float vx = 0.f, vy = 0.f, wsx = 0.f, wsy = 0.f;      // window sum-square in float32, frame order, as librosa
+            for (int f = f0; f <= f1; ++f) {
+                const int j = n - f * kHop;                      // even, 0..2046
+                const float2 F = reinterpret_cast<const float2*>(lds + (f % kIstftSlabs) * fft::kSlabFloats)[fft::zpos(j >> 1)];
+                const float2 w = *reinterpret_cast<const float2*>(&tb->window[j]);
+                vx += w.x * (F.x * (1.0f / 1024.0f));
+                vy += w.y * (-F.y * (1.0f / 1024.0f));
+                wsx += w.x * w.x;
+                wsy += w.y * w.y;
+            }
+            if (wsx > 1.17549435e-38f) vx = vx / wsx;
+            if (wsy > 1.17549435e-38f) vy = vy / wsy;
+            const int src = n - kNfft / 2;                       // centre trim; n even, so src and src + 1 share their fate below
+            const int i = src - crop;
+            if (i >= 0 && i < dst_len) out[i] = src < length ? vx : 0.f;
+            if (i + 1 >= 0 && i + 1 < dst_len) out[i + 1] = src + 1 < length ? vy : 0.f;
         }
-        out[i] = v;
+        __syncthreads();                                         // the next round overwrites the slabs of round r - 1
     }
+    // samples past the reach of the last frame (only when the spectrogram is shorter than `length` asks for)
+    for (int i = 4 * rounds * kHop - kNfft / 2 - crop + tid; i < dst_len; i += 256)
+        if (i >= 0) out[i] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
