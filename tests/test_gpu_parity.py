@@ -139,8 +139,25 @@ def test_simple_model_matches_reference_goldens(ops, dev, golden_simple, tag):
     assert np.abs(head - golden_simple["logits" + tag]).max() <= 1e-5
 
 
-@pytest.mark.parametrize("arch,width,batch", [("simple", 32, 33), ("simple", 17, 5), ("simple", 1, 2),
-                                              ("full", 32, 9), ("full", 31, 3)])
+_ORACLE_CACHE = {}
+
+
+def _oracle_logits(arch, width, batch, x, sd):
+    """Closed-form numpy oracle for small batches; its torch restatement (pinned to it in tests/test_oracle_model.py) for the
+    large ones, computed once for both conv maths."""
+    key = (arch, width, batch)
+    if key not in _ORACLE_CACHE:
+        if batch <= 64:
+            _ORACLE_CACHE[key] = model_oracle.forward_np(x, sd)
+        else:
+            with torch.no_grad():
+                _ORACLE_CACHE[key] = model_oracle.torch_module_from_state_dict(sd)(torch.from_numpy(x)).numpy()
+    return _ORACLE_CACHE[key]
+
+
+@pytest.mark.parametrize("arch,width,batch", [("simple", 32, 33), ("simple", 17, 5), ("simple", 1, 2), ("simple", 31, 300),
+                                              ("simple", 8, 258), ("full", 32, 9), ("full", 31, 3), ("full", 16, 4),
+                                              ("full", 1, 2), ("full", 23, 258)])
 def test_model_module_matches_oracle(dev, arch, width, batch):
     sd = pkg.synth.make_state_dict(arch, seed=7)
     x = (pkg.synth.normal(11, batch * 80 * width).astype(np.float32).reshape(batch, 1, 80, width) * 15 - 35)
@@ -148,7 +165,7 @@ def test_model_module_matches_oracle(dev, arch, width, batch):
     with torch.no_grad():
         y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
     assert y.shape == (batch, 2)
-    assert np.abs(y - model_oracle.forward_np(x, sd)).max() <= LOGIT_TOL
+    assert np.abs(y - _oracle_logits(arch, width, batch, x, sd)).max() <= LOGIT_TOL
 
 
 def test_state_dict_round_trip_and_repack_on_update(dev, golden_simple):
