@@ -22,4 +22,10 @@ model_oracle.py  closed-form restatement of `SimpleWakewordModel.forward`
                  `WakewordModel.forward` (wakeword_training_script.py:167-184).
                  PINNED: tests/golden/model_simple_*.npz were produced by
                  importing the reference module itself (tests/golden/make_golden.py).
+decode_oracle.py restatement of load_audio's numeric part + normalise + crop/pad
+                 (wakeword_training_script.py:65-83,125-133); resampler = scipy's polyphase design,
+                 UNPINNED against librosa's soxr_hq.
+augment_oracle.py restatement of augment_audio (wakeword_training_script.py:103-123): librosa 0.10.1's
+                 stft / phase_vocoder / istft, resampy's kaiser_best as the resampler stand-in, the
+                 build's hash generator as the noise stand-in.  UNPINNED against librosa.
 """
