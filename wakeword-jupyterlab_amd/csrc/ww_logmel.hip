@@ -19,27 +19,35 @@
 
 namespace ww {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kThreads = kWavesPerBlock * 64;
 // wave slab: 1024 complex = 2048 floats (+4 keeps 16-byte alignment and staggers the slabs over the banks)
 constexpr int kSlab = 2048 + 4;
 constexpr int kMelStride = kFrames + 1;
-// LDS map (floats): slabs | mel | reduce scratch | piece index | filter index | pass-2 twiddles | pair twiddles.
-// Window, pass-1 twiddles and piece weights are read through L1 from the global table (25 KB less LDS per workgroup:
-// three workgroups per CU instead of two).
 // The per-wave piece sums live in the upper half of the wave's slab (the power spectrum only needs floats 0..1024).
 constexpr int kPartialInSlab = 1032;
 static_assert(kPartialInSlab + kPieces <= kSlab, "piece sums must fit behind the power spectrum");
-constexpr int kOffMel = kWavesPerBlock * kSlab;
-constexpr int kOffRed = kOffMel + kMels * kMelStride;
-constexpr int kOffPinfo = kOffRed + 16;                 // [kPieces] ints
-constexpr int kOffFp0 = kOffPinfo + kPieces;            // [80] ints
-constexpr int kOffFcnt = kOffFp0 + kMels;               // [80] ints
-constexpr int kOffTw2 = kOffFcnt + kMels;               // [7][16] float2
-constexpr int kOffTwp = kOffTw2 + 7 * 16 * 2;           // [512] float2
-constexpr int kLdsFloats = kOffTwp + 512 * 2;
-constexpr int kBlocksPerCu = 3;
-static_assert(kOffPinfo % 4 == 0 && kOffTw2 % 4 == 0 && kOffTwp % 2 == 0, "LDS table alignment");
+
+// LDS map (floats): slabs | mel | reduce scratch | piece index | filter index | pass-2 twiddles | pair twiddles.
+// Window, pass-1 twiddles and piece weights are read through L1 from the global table (25 KB less LDS per workgroup).
+// WAVES = 4: the throughput form, three workgroups per CU, persistent over clips.
+// WAVES = 8: the latency form for batches of at most one clip per CU (streaming): a clip's 32 frames take 4 rounds
+//            instead of 8, one 83 KB workgroup per CU.
+template <int WAVES>
+struct K1Layout {
+    static constexpr int kWaves = WAVES;
+    static constexpr int kThreads = WAVES * 64;
+    static constexpr int kOffMel = WAVES * kSlab;
+    static constexpr int kOffRed = kOffMel + kMels * kMelStride;
+    static constexpr int kOffPinfo = kOffRed + 16;          // [kPieces] ints
+    static constexpr int kOffFp0 = kOffPinfo + kPieces;     // [80] ints
+    static constexpr int kOffFcnt = kOffFp0 + kMels;        // [80] ints
+    static constexpr int kOffTw2 = kOffFcnt + kMels;        // [7][16] float2
+    static constexpr int kOffTwp = kOffTw2 + 7 * 16 * 2;    // [512] float2
+    static constexpr int kLdsFloats = kOffTwp + 512 * 2;
+    static constexpr int kWavesPerSimd = WAVES == 4 ? 3 : 2;   // launch bound: 3 x 4 waves or 1 x 8 waves per CU
+    static constexpr int kBlocksPerCu = WAVES == 4 ? 3 : 1;
+    static_assert(kOffPinfo % 4 == 0 && kOffTw2 % 4 == 0 && kOffTwp % 2 == 0, "LDS table alignment");
+    static_assert(kFrames % WAVES == 0 && WAVES <= 8, "frames are dealt to the waves in whole rounds; red[] holds 16 floats");
+};
 
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -139,12 +147,16 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do {} while (0)
 #endif
 
-template <bool RING>
-__global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
+template <bool RING, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
                                                              int clip_len, int n_clips, int normalize,
                                                              const int32_t* __restrict__ ring_pos_p, int ring_len,
                                                              const LogmelTables* __restrict__ tb,
                                                              float* __restrict__ out) {
+    using L = K1Layout<WAVES>;
+    constexpr int kWavesPerBlock = WAVES, kThreads = L::kThreads;
+    constexpr int kOffMel = L::kOffMel, kOffRed = L::kOffRed, kOffPinfo = L::kOffPinfo, kOffFp0 = L::kOffFp0,
+                  kOffFcnt = L::kOffFcnt, kOffTw2 = L::kOffTw2, kOffTwp = L::kOffTwp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mel = lds + kOffMel;                                 // [80][33]
     float* red = lds + kOffRed;                                 // [16]
@@ -414,10 +426,12 @@ __global__ __launch_bounds__(kThreads, kBlocksPerCu) void logmel_kernel(const fl
             mmax = fmaxf(mmax, __shfl_xor(mmax, off));
             peak = fmaxf(peak, __shfl_xor(peak, off));
         }
-        if (lane == 0) { red[wave] = mmax; red[4 + wave] = peak; }
+        if (lane == 0) { red[wave] = mmax; red[kWavesPerBlock + wave] = peak; }
         __syncthreads();
-        mmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        peak = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        mmax = red[0];
+        peak = red[kWavesPerBlock];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) { mmax = fmaxf(mmax, red[w]); peak = fmaxf(peak, red[kWavesPerBlock + w]); }
 
         // power_to_db(S, ref=np.max, amin=1e-10, top_db=80): NaN must propagate (silent clip, 0/0)
         const float amin = 1e-10f;
@@ -451,28 +465,40 @@ extern "C" __attribute__((visibility("default"))) int ww_debug_stamps(unsigned l
 }
 #endif
 
+template <int WAVES>
+static int launch_logmel_w(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
+                           const int32_t* ring_pos, int64_t ring_len, float* logmel, const LogmelTables* tb, hipStream_t stream) {
+    using L = K1Layout<WAVES>;
+    const int64_t resident = int64_t(device_cu_count()) * L::kBlocksPerCu;   // what LDS and VGPRs admit per CU
+    const int grid = int(n_clips < resident ? n_clips : resident);
+    const size_t lds_bytes = sizeof(float) * L::kLdsFloats;
+    static bool attr[64] = {};          // > 64 KiB of dynamic LDS (8-wave form) needs the opt-in once per device
+    int dev = 0;
+    WW_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<true, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        attr[dev] = true;
+    }
+    if (ring_pos)
+        hipLaunchKernelGGL((logmel_kernel<true, WAVES>), dim3(grid), dim3(L::kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
+                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
+    else
+        hipLaunchKernelGGL((logmel_kernel<false, WAVES>), dim3(grid), dim3(L::kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
+                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
 int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
                   const int32_t* ring_pos, int64_t ring_len, float* logmel, hipStream_t stream) {
     if (n_clips == 0) return WW_OK;
     const LogmelTables* tb = device_tables();
     if (!tb) return WW_EHIP;
-    const int64_t resident = int64_t(device_cu_count()) * kBlocksPerCu;   // what LDS and VGPRs admit per CU
-    const int grid = int(n_clips < resident ? n_clips : resident);
-    const size_t lds_bytes = sizeof(float) * kLdsFloats;
-    static bool lds_attr_set = false;   // just over 64 KiB of dynamic LDS: needs the opt-in once per process
-    if (!lds_attr_set) {
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-        lds_attr_set = true;
-    }
-    if (ring_pos)
-        hipLaunchKernelGGL(logmel_kernel<true>, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
-                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
-    else
-        hipLaunchKernelGGL(logmel_kernel<false>, dim3(grid), dim3(kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
-                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
-    WW_HIP(hipGetLastError());
-    return WW_OK;
+    // at most one clip per CU (streaming, small batches): the 8-wave latency form; otherwise the 4-wave throughput form
+    if (n_clips <= device_cu_count())
+        return launch_logmel_w<8>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, stream);
+    return launch_logmel_w<4>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, stream);
 }
 
 }  // namespace ww
