@@ -107,6 +107,22 @@ def test_packed_weight_image_layout(arch):
     nt, dx, dy, lane, j = np.meshgrid(np.arange(4), np.arange(3), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
     want16 = w2[16 * nt + (lane & 15), 8 * (lane >> 4) + j, dy, dx] * 2.0 ** S
     assert np.abs((h16[:, :, 0] + h16[:, :, 1]).reshape(4, 3, 3, 64, 8) - want16).max() <= np.abs(want16).max() * 2.0 ** -21
+    # LSTM W_ih split for the 16x16x32 f16 MFMA: [K/32][48 ntile][hi/lo][64 lanes][8]; column c = 16 nt + lane%16 in the
+    # same (hb, gate, u) order as the f32 image, k = 32 kb + 8 (lane//16) + j
+    Ks = [64 if arch == "simple" else 128, 256]
+    lh = [take(K // 32 * 48 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(K // 32, 48, 2, 64, 8) for K in Ks]
+    hs = take(4)
+    goff = np.array([0, 512, 768])
+    for layer, K in enumerate(Ks):
+        w_ih = sd[f"lstm.weight_ih_l{layer}"].astype(np.float64)
+        S = -int(round(np.log2(float(hs[layer]))))
+        live = w_ih[np.concatenate([np.arange(0, 256), np.arange(512, 1024)])]
+        assert 2.0 ** 12 <= np.abs(live).max() * 2.0 ** S < 2.0 ** 13
+        kb, nt, lane, j = np.meshgrid(np.arange(K // 32), np.arange(48), np.arange(64), np.arange(8), indexing="ij")
+        c = 16 * nt + (lane & 15)
+        row = goff[(c % 96) // 32] + 32 * (c // 96) + c % 32
+        want = w_ih[row, 32 * kb + 8 * (lane >> 4) + j] * 2.0 ** S
+        assert np.abs((lh[layer][:, :, 0] + lh[layer][:, :, 1]) - want).max() <= np.abs(want).max() * 2.0 ** -21
     assert o == p.size
 
 

@@ -141,11 +141,151 @@ __global__ __launch_bounds__(512) void lstm_fc_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-precision form (conv math f16x3): the gate GEMMs on v_mfma_f32_16x16x32_f16 with activations and weights as
+// f16 hi + lo pairs (three MFMAs per product block, fp32 accumulate), 3/16 of the exact-f32 form's matrix-pipe cycles.
+// The workgroup is bound by its own latency chain (layer 0 -> layer 1 -> fc on one CU): the kernel takes the same time
+// at 16 and at 4096 clips, and two thirds of it were f32 MFMA cycles.
+// Activations live in LDS as two f16 planes [16 clips][K + 8]: lane (clip m, kq) reads its 8 consecutive k of a 32-k block
+// with one ds_read_b128 per plane (row stride (K + 8) halfs: conflict-free).
+// ------------------------------------------------------------------------------------------------
+using half8_t = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4_t = __attribute__((ext_vector_type(4))) uint32_t;
+
+template <int K>
+__device__ __forceinline__ void lstm_layer_h(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                             const u32x4_t* __restrict__ wt, float descale, const float* __restrict__ bias,
+                                             int hb, int lane, _Float16* __restrict__ out_h, _Float16* __restrict__ out_l,
+                                             float* __restrict__ out_f, int out_stride) {
+    constexpr int KS = K + 8, KB = K / 32, D = 2;
+    const int col = lane & 15, kq = lane >> 4;
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][h][j] = 0.f;
+    const _Float16* ah_p = xh + col * KS + kq * 8;
+    const _Float16* al_p = xl + col * KS + kq * 8;
+    // wave hb's six N-tiles are packed tiles 6 hb .. 6 hb + 5; per k-block and tile: [hi,lo][64 lanes] x 16 bytes
+    const u32x4_t* b_p = wt + (int64_t(hb) * 6 * 2) * 64 + lane;
+    constexpr int kTileStride = 2 * 64, kKbStride = (kGateCols / 16) * 2 * 64;
+    u32x4_t bw[D][6][2];
+#pragma unroll
+    for (int d = 0; d < D && d < KB; ++d)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            bw[d][t][0] = b_p[int64_t(d) * kKbStride + t * kTileStride];
+            bw[d][t][1] = b_p[int64_t(d) * kKbStride + t * kTileStride + 64];
+        }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const half8_t ah = *reinterpret_cast<const half8_t*>(ah_p + 32 * kb);
+        const half8_t al = *reinterpret_cast<const half8_t*>(al_p + 32 * kb);
+        u32x4_t bc[6][2];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { bc[t][0] = bw[kb % D][t][0]; bc[t][1] = bw[kb % D][t][1]; }
+        if (kb + D < KB) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                bw[kb % D][t][0] = b_p[int64_t(kb + D) * kKbStride + t * kTileStride];
+                bw[kb % D][t][1] = b_p[int64_t(kb + D) * kKbStride + t * kTileStride + 64];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const half8_t bh = __builtin_bit_cast(half8_t, bc[t][0]), bl = __builtin_bit_cast(half8_t, bc[t][1]);
+            acc[t >> 1][t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t >> 1][t & 1], 0, 0, 0);
+            acc[t >> 1][t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t >> 1][t & 1], 0, 0, 0);
+            acc[t >> 1][t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t >> 1][t & 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // D: lane&15 = hidden unit within the half, register j <-> clip 4*(lane>>4) + j
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int u = 16 * h + col;
+        const float b_i = bias[hb * 96 + u], b_g = bias[hb * 96 + 32 + u], b_o = bias[hb * 96 + 64 + u];
+        const int unit = 32 * hb + u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int clip = 4 * kq + j;
+            const float c = sigmoidf_(fmaf(acc[0][h][j], descale, b_i)) * tanhf_(fmaf(acc[1][h][j], descale, b_g));
+            const float hv = sigmoidf_(fmaf(acc[2][h][j], descale, b_o)) * tanhf_(c);
+            if (out_f) {
+                out_f[clip * out_stride + unit] = hv;
+            } else {
+                const _Float16 hi = static_cast<_Float16>(hv);
+                out_h[clip * out_stride + unit] = hi;
+                out_l[clip * out_stride + unit] = static_cast<_Float16>(hv - static_cast<float>(hi));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void lstm_fc_h_kernel(const float* __restrict__ pooled, int n, int C,
+                                                        const u32x4_t* __restrict__ w0, const float* __restrict__ b0,
+                                                        const u32x4_t* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ hs, const float* __restrict__ fcw,
+                                                        const float* __restrict__ fcb, float* __restrict__ logits,
+                                                        float* __restrict__ prob) {
+    constexpr int kXS = 128 + 8, kHS16 = kHidden + 8;
+    __shared__ __attribute__((aligned(16))) _Float16 xh[kClipsPerBlock * kXS], xl[kClipsPerBlock * kXS];
+    __shared__ __attribute__((aligned(16))) _Float16 h0h[kClipsPerBlock * kHS16], h0l[kClipsPerBlock * kHS16];
+    __shared__ __attribute__((aligned(16))) float h1[kClipsPerBlock * kHS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int clip0 = blockIdx.x * kClipsPerBlock;
+    const int xs = C + 8;
+
+    for (int i = tid; i < kClipsPerBlock * C; i += 512) {
+        const int r = i / C, k = i - r * C;
+        const float v = (clip0 + r < n) ? pooled[int64_t(clip0 + r) * C + k] : 0.f;
+        const _Float16 hi = static_cast<_Float16>(v);
+        xh[r * xs + k] = hi;
+        xl[r * xs + k] = static_cast<_Float16>(v - static_cast<float>(hi));
+    }
+    __syncthreads();
+    if (C == 64) lstm_layer_h<64>(xh, xl, w0, hs[0], b0, wave, lane, h0h, h0l, nullptr, kHS16);
+    else lstm_layer_h<128>(xh, xl, w0, hs[0], b0, wave, lane, h0h, h0l, nullptr, kHS16);
+    __syncthreads();
+    lstm_layer_h<kHidden>(h0h, h0l, w1, hs[1], b1, wave, lane, nullptr, nullptr, h1, kHS);
+    __syncthreads();
+    {
+        const int o = tid >> 4, part = tid & 15, clip = o >> 1, cls = o & 1;
+        const float* hrow = h1 + clip * kHS;
+        const float* wrow = fcw + cls * kHidden;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = part * 16; k < part * 16 + 16; ++k) acc = fmaf(hrow[k], wrow[k], acc);
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 8);
+        const float logit = acc + fcb[cls];
+        const float other = __shfl_xor(logit, 16);
+        if (part == 0 && clip0 + clip < n) {
+            logits[int64_t(clip0 + clip) * 2 + cls] = logit;
+            if (prob && cls == 1) prob[clip0 + clip] = 1.0f / (1.0f + expf(other - logit));
+        }
+    }
+}
+
 int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_conv, float* logits, float* prob,
                    hipStream_t stream) {
     if (n == 0) return WW_OK;
     const PackedLayout L = packed_layout(n_conv);
     const int grid = int((n + kClipsPerBlock - 1) / kClipsPerBlock);
+    if (conv_math_mode() == 1) {
+        hipLaunchKernelGGL(lstm_fc_h_kernel, dim3(grid), dim3(512), 0, stream, pooled, int(n), L.c_last,
+                           reinterpret_cast<const u32x4_t*>(packed + L.l0_h), packed + L.l0_b,
+                           reinterpret_cast<const u32x4_t*>(packed + L.l1_h), packed + L.l1_b, packed + L.lstm_hs,
+                           packed + L.fc_w, packed + L.fc_b, logits, prob);
+        WW_HIP(hipGetLastError());
+        return WW_OK;
+    }
     hipLaunchKernelGGL(lstm_fc_kernel, dim3(grid), dim3(512), 0, stream, pooled, int(n), L.c_last, packed + L.l0_w,
                        packed + L.l0_b, packed + L.l1_w, packed + L.l1_b, packed + L.fc_w, packed + L.fc_b, logits,
                        prob);

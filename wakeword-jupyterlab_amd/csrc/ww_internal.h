@@ -85,6 +85,9 @@ struct PackedLayout {
     int64_t conv3_h;   // (n_conv 3) conv3 split-precision B operands for 16x16x32: [8 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64][4]
     int64_t conv3_hs;  // [4]: 2^-S3
     int64_t conv2_h16; // same weights for v_mfma_f32_16x16x32_f16: [4 ntile][9 kstep = dx*3+dy][hi,lo][64 lanes][4 dwords]
+    int64_t l0_h;      // W_ih l0 split for v_mfma_f32_16x16x32_f16: [K/32][48 ntile][hi,lo][64 lanes][4 dwords], columns as l0_w
+    int64_t l1_h;      // same for layer 1 (K = 256)
+    int64_t lstm_hs;   // [4]: 2^-S of layer 0, 2^-S of layer 1, 0, 0
     int64_t total;
 };
 PackedLayout packed_layout(int n_conv);

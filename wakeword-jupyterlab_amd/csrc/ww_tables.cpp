@@ -170,6 +170,9 @@ PackedLayout packed_layout(int n_conv) {
     L.conv3_hs = n_conv == 3 ? take(4) : -1;
     L.conv1_h = take(2 * 64 * 4);
     L.conv2_h16 = take(4 * 9 * 2 * 64 * 4);
+    L.l0_h = take(int64_t(L.c_last / 32) * 48 * 2 * 64 * 4);
+    L.l1_h = take(int64_t(kHidden / 32) * 48 * 2 * 64 * 4);
+    L.lstm_hs = take(4);
     L.total = o;
     return L;
 }
@@ -295,6 +298,41 @@ static void pack_lstm(const float* w_ih, const float* b_ih, const float* b_hh, i
             }
 }
 
+// W_ih [4*hidden][K] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16, same column order as pack_lstm
+// (column c = (hb*3 + gate)*32 + u): k-block kb covers k = 32 kb .. 32 kb + 31, N-tile nt = c / 16; lane (n = lane&15,
+// kq = lane>>4) holds B[k = 8 kq + j][n] = W'[row(16 nt + n)][32 kb + 8 kq + j], j = 0..7.  W' = W * 2^S with max |W'| in
+// [2^12, 2^13).  Returns the descale 2^-S.
+static float pack_lstm_f16x3(const float* w_ih, int K, float* out_words) {
+    const int goff[3] = {0, 2 * kHidden, 3 * kHidden};   // i, g, o
+    float wmax = 0.f;
+    for (int g = 0; g < 3; ++g)
+        for (int r = 0; r < kHidden; ++r)
+            for (int k = 0; k < K; ++k) wmax = std::fmax(wmax, std::fabs(w_ih[int64_t(goff[g] + r) * K + k]));
+    int S = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) S = 12 - int(std::floor(std::log2(wmax)));
+    if (S > 24) S = 24;
+    if (S < -8) S = -8;
+    const float scale = std::ldexp(1.0f, S);
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
+    for (int kb = 0; kb < K / 32; ++kb)
+        for (int nt = 0; nt < kGateCols / 16; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * nt + (lane & 15), hb = c / 96, g = (c % 96) / 32, u = c % 32;
+                    const int row = goff[g] + 32 * hb + u, k = 32 * kb + 8 * (lane >> 4) + j;
+                    const float v = w_ih[int64_t(row) * K + k] * scale;
+                    const _Float16 hi = static_cast<_Float16>(v);
+                    const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
+                    uint16_t hb16, lb16;
+                    std::memcpy(&hb16, &hi, 2);
+                    std::memcpy(&lb16, &lo, 2);
+                    const int64_t base = ((int64_t(kb) * (kGateCols / 16) + nt) * 2) * 64 * 8;   // in f16 units
+                    o16[base + lane * 8 + j] = hb16;
+                    o16[base + 64 * 8 + lane * 8 + j] = lb16;
+                }
+    return std::ldexp(1.0f, -S);
+}
+
 }  // namespace ww
 
 using namespace ww;
@@ -357,6 +395,8 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     if (sd->n_conv == 3) out[L.conv3_hs] = pack_conv3_f16x3(sd->conv_weight[2], out + L.conv3_h);
     pack_conv1_f16x3(sd->conv_weight[0], sd->conv_bias[0], out + L.conv1_h);
     out[L.conv2_hs] = pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h16);
+    out[L.lstm_hs] = pack_lstm_f16x3(sd->lstm_weight_ih[0], L.c_last, out + L.l0_h);
+    out[L.lstm_hs + 1] = pack_lstm_f16x3(sd->lstm_weight_ih[1], kHidden, out + L.l1_h);
     return WW_OK;
 }
 
