@@ -261,6 +261,7 @@ def main():
                 "kernel_ms_sum": k1_ms + k2_ms + k3_ms,
             },
             "device": nat.device_info(),
+            "sync_timeouts": int(nat.lib.ww_sync_timeouts()),      # bounded in-kernel waits that expired: must be 0
         }
         if k2_f32_ms is not None:
             out["roofline_f32_exact"] = {

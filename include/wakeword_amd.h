@@ -66,6 +66,9 @@ WW_API const char* ww_last_error(void);
 WW_API int ww_init(void);
 /* Device facts used by bench.py for the roofline denominator: number of CUs, max clock (kHz). */
 WW_API int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len);
+/* Health check (synchronises the device): how many bounded in-kernel waits of the conv kernel's producer/consumer
+ * protocol have expired since the library was loaded.  Always 0 unless the protocol is broken; negative = error code. */
+WW_API int ww_sync_timeouts(void);
 
 /* Arithmetic of the conv2 implicit GEMM (94 of the model's 96.5 MFLOP per clip); process-wide, default F16X3.
  *   WW_CONV_MATH_F32    v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (an fmaf chain)

@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     if (!have_gpu) {
         /* no CPU fallback: every launch fails loudly without a gfx950 device */
         CHECK(ww_init() == WW_ENODEVICE);
+        CHECK(ww_sync_timeouts() == WW_ENODEVICE);
         CHECK(ww_logmel_f32((const float*)16, 1, 16000, 16000, 1, (float*)16, NULL) == WW_ENODEVICE);
     }
     printf("abi_host_check OK\n");

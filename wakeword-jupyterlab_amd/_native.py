@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ww_set_conv_math": (C.c_int, [C.c_int]),
     "ww_get_conv_math": (C.c_int, []),
     "ww_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "ww_sync_timeouts": (C.c_int, []),
     "ww_mel_filterbank_host": (C.c_int, [C.c_void_p]),
     "ww_hann_window_host": (C.c_int, [C.c_void_p]),
     "ww_resample_taps_host": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -194,6 +194,13 @@ int ww_init(void) {
     return device_tables() ? WW_OK : WW_EHIP;
 }
 
+int ww_sync_timeouts(void) {
+    if (int rc = require_gfx950()) return rc;
+    unsigned int c = 0;
+    if (int rc = sync_timeouts(&c)) return rc;
+    return int(c > 0x7fffffffu ? 0x7fffffffu : c);
+}
+
 int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len) {
     if (int rc = require_gfx950()) return rc;
     int dev = 0;

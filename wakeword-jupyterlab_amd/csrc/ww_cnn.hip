@@ -322,7 +322,10 @@ __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh,
 }
 
 // Workgroup-local progress counters in LDS (monotonic).  signal = release add by one wave; wait = acquire poll.  The
-// poll is bounded (~0.2 s): a protocol bug would then show up as a parity failure, not as a hung GPU.
+// poll is bounded (~0.2 s): a protocol bug then cannot hang the GPU; it is counted in g_sync_timeouts, which the host
+// reads with ww_sync_timeouts() (the GPU tests assert that it stays 0).
+__device__ unsigned int g_sync_timeouts;
+
 __device__ __forceinline__ void flag_signal(uint32_t* f) {
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -331,6 +334,7 @@ __device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target) {
         if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return;
         __builtin_amdgcn_s_sleep(1);
     }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sync_timeouts, 1u);
 }
 
 #ifdef WW_STAMPS
@@ -784,6 +788,11 @@ __global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restric
         if (g + 1 < steps) stash(g + 1);     // the other buffer: last read in step g-1, retired by the barrier below
         __syncthreads();
     }
+}
+
+int sync_timeouts(unsigned int* count) {
+    WW_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_sync_timeouts), sizeof(unsigned int)));
+    return WW_OK;
 }
 
 int64_t cnn_scratch_bytes(int64_t n, int n_conv) {

@@ -102,6 +102,7 @@ int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment
                    int64_t out_stride, void* workspace, hipStream_t stream);
 int64_t augment_workspace_bytes(int64_t n);
 void build_kaiser_best(float* out /*[32769]*/);
+int sync_timeouts(unsigned int* count);   // bounded LDS-counter waits that expired (must be 0)
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
                     float* pooled, hipStream_t stream);
 // conv math: 0 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split (3 x v_mfma_f32_32x32x16_f16 per product block)
