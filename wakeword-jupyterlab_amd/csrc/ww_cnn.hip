@@ -389,8 +389,8 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         __builtin_amdgcn_s_setprio(3);
     }
     // progress counters: tiles produced x 4 producer waves, bands consumed x 8 consumer waves, mel planes loaded x 4
-    __shared__ uint32_t prod_done, cons_done, mel_done;
-    if (tid == 0) { prod_done = 0u; cons_done = 0u; mel_done = 0u; }
+    __shared__ uint32_t prod_done, cons_done[2], mel_done;
+    if (tid == 0) { prod_done = 0u; cons_done[0] = 0u; cons_done[1] = 0u; mel_done = 0u; }
     // zero fill; column 34 of every row of the two hi planes is the constant 1.0 (f16 0x3C00) of the bias tap
     for (int i = tid; i < kC2h16Lds / 4; i += 768) {
         const int w = i - 2 * kH16Act / 4;               // dword index inside the four planes (hi, lo, hi, lo)
@@ -458,12 +458,15 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     // One loop per role (the consumers' resident B operands and accumulators are then not live in the producers' code)
     // and NO workgroup barrier in the steady state; the roles meet through the three counters:
     //   a consumer starts band g when tile g is complete                          (prod_done >= 4 (g + 1))
-    //   a producer writes tile g once every consumer has finished band g - 2      (cons_done >= 8 (g - 1), same buffer)
+    //   a producer writes tile g once every consumer has finished band g - 2      (cons_done[g & 1] >= 8 (g / 2), same buffer)
     //   the four producers advance tile by tile                                   (prod_done >= 4 g): the halo copy
     //     reads tile g - 1, which a producer running ahead would be overwriting with tile g + 1; the same wait frees
     //     the mel planes of the previous clip for the next load
     // so a consumer wave that is done early flows into the next band instead of idling at a barrier while its SIMD
-    // sibling finishes (-4 %).
+    // sibling finishes (-4 %).  The consumers' counter is split by tile buffer (band parity): consumers are NOT in lock
+    // step -- a fast wave may finish band g - 1 before a slow one finishes g - 2 -- so one running total could reach
+    // 8 (g - 1) with a reader of the buffer still busy; a wave cannot be two bands (one parity) ahead, because the tile it
+    // would need is gated by exactly this wait.  The producers' counter is exact because they advance tile by tile.
     if (!consumer) {
         if (steps > 0) { load_mel(0); flag_signal(&mel_done); }
         for (int g = 0; g < steps; ++g) {
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             CSTAMP(0);
             flag_wait(&prod_done, 4u * unsigned(g));
             if (band == 0) flag_wait(&mel_done, 4u * unsigned(k + 1));
-            if (g >= 2) flag_wait(&cons_done, 8u * unsigned(g - 1));
+            if (g >= 2) flag_wait(&cons_done[g & 1], 8u * unsigned(g / 2));
             CSTAMP(4);
             produce(g);
             flag_signal(&prod_done);
@@ -486,7 +489,10 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
         CSTAMP(0);
         flag_wait(&prod_done, 4u * unsigned(g + 1));                   // tile g complete
-        if (POOL && band == 0 && g > 0 && wave == 0) flag_wait(&cons_done, 8u * unsigned(g));   // red[] of clip k - 1 complete
+        if (POOL && band == 0 && g > 0 && wave == 0) {                // red[] of clip k - 1 complete (g is even)
+            flag_wait(&cons_done[0], 8u * unsigned(g / 2));
+            flag_wait(&cons_done[1], 8u * unsigned(g / 2));
+        }
         CSTAMP(4);
         {
             if (POOL && band == 0 && g > 0 && wave == 0) write_pooled(k - 1);
@@ -573,11 +579,12 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             }
             CSTAMP(2);
         }
-        flag_signal(&cons_done);
+        flag_signal(&cons_done[g & 1]);
     }
     }
     if (POOL && consumer && wave == 0 && steps > 0) {
-        flag_wait(&cons_done, 8u * unsigned(steps));
+        flag_wait(&cons_done[0], 8u * unsigned(steps / 2));       // steps = 10 x clips: even
+        flag_wait(&cons_done[1], 8u * unsigned(steps / 2));
         write_pooled(my_clips - 1);
     }
 #ifdef WW_STAMPS
