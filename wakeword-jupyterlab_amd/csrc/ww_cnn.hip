@@ -326,14 +326,22 @@ __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh,
 // reads with ww_sync_timeouts() (the GPU tests assert that it stays 0).
 __device__ unsigned int g_sync_timeouts;
 
+// The fences are executed by EVERY lane (the counter itself only by lane 0 / read by all): release and acquire order the
+// LDS accesses of the work-item that executes them, and a tile is written and read by all 64 lanes of a wave.
 __device__ __forceinline__ void flag_signal(uint32_t* f) {
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target) {
+#pragma unroll 1
     for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return;
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            return;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_sync_timeouts, 1u);
 }
 
