@@ -12,7 +12,8 @@
  *     pointer is ordinary host memory.  No torch / C++ types cross this boundary.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All launch
  *     functions are asynchronous on that stream, allocate nothing, never synchronise and are
- *     therefore capturable into a hipGraph once ww_init() has run on the device.
+ *     therefore capturable into a hipGraph once ww_init() has run on the device (exceptions, stated
+ *     at the function: ww_augment_f32 reads its plans from host memory and synchronises the stream).
  *   - return value: WW_OK (0) or a negative WW_E* code; ww_last_error() gives the message of the
  *     calling thread's most recent failure.  Nothing falls back to a CPU path: without a usable
  *     gfx950 device every launch function fails with WW_ENODEVICE.
@@ -70,12 +71,13 @@ WW_API int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len);
  * protocol have expired since the library was loaded.  Always 0 unless the protocol is broken; negative = error code. */
 WW_API int ww_sync_timeouts(void);
 
-/* Arithmetic of the conv2 implicit GEMM (94 of the model's 96.5 MFLOP per clip); process-wide, default F16X3.
- *   WW_CONV_MATH_F32    v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (an fmaf chain)
+/* Arithmetic of the implicit GEMMs (conv1/conv2/conv3 and the LSTM gate GEMMs: all but ~1 % of the model's flops);
+ * process-wide, default F16X3.
+ *   WW_CONV_MATH_F32    v_mfma_f32_32x32x2_f32 / 16x16x4_f32: exact fp32 products and accumulation (an fmaf chain)
  *   WW_CONV_MATH_F16X3  each fp32 operand carried as two f16 halves (22 significant bits), every product block as
- *                       three v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-21 relative error per product
- *                       (PyTorch's own default for convolutions on the reference's GPU is TF32, 2^-11), 3/16 of
- *                       the matrix-core cycles.  Requires conv1 activations < 65504. */
+ *                       three f16 MFMAs (v_mfma_f32_16x16x32_f16) with fp32 accumulation: ~2^-21 relative error per
+ *                       product (PyTorch's own default for convolutions on the reference's GPU is TF32, 2^-11), 3/16
+ *                       of the matrix-core cycles.  Requires activations < 65504. */
 #define WW_CONV_MATH_F32 0
 #define WW_CONV_MATH_F16X3 1
 WW_API int ww_set_conv_math(int mode);
@@ -134,7 +136,8 @@ typedef struct ww_augment_plan {
 } ww_augment_plan;
 WW_API int64_t ww_augment_workspace_bytes(int64_t n_clips);
 /* pcm_dev [n_clips] rows of 16000 samples at pcm_dev + i*clip_stride (16-byte aligned, clip_stride % 4 == 0);
- * plans_host [n_clips] in HOST memory (read before the call returns); out_dev [n_clips][16000], may alias pcm_dev;
+ * plans_host [n_clips] in HOST memory (uploaded and the stream synchronised before the call returns: not graph-
+ * capturable); out_dev [n_clips][16000], may alias pcm_dev;
  * workspace_dev >= ww_augment_workspace_bytes(n_clips), 256-byte aligned. */
 WW_API int ww_augment_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, const ww_augment_plan* plans_host,
                    float* out_dev, void* workspace_dev, ww_stream_t stream);
