@@ -226,7 +226,7 @@ def main():
             "metric": METRIC, "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 in/out/accumulate; conv2 products as f16x3 split (3 f16 MFMAs per fp32 product block, ~2^-21 rel.)" if split else "f32",
+            "dtype": "f32 in/out/accumulate; conv and LSTM-gate GEMM products as f16x3 split (3 f16 MFMAs per fp32 product block, ~2^-21 rel.)" if split else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[2]: batch={B} 1 s/16 kHz clips per GPU, full log-mel + CNN + LSTM HIP forward "
