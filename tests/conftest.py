@@ -19,3 +19,17 @@ def pytest_configure(config):
 def golden_simple():
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, "model_simple_seed1234.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_full():
+    """3-conv WakewordModel outputs produced by the reference's own class text (tests/golden/make_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "model_full_seed1234.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_grads():
+    """loss + parameter gradients of the reference SimpleWakewordModel (tests/golden/make_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "grads_simple_seed1234.npz")))

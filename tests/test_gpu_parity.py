@@ -139,6 +139,20 @@ def test_simple_model_matches_reference_goldens(ops, dev, golden_simple, tag):
     assert np.abs(head - golden_simple["logits" + tag]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("tag", ["32", "31"])
+def test_full_model_matches_reference_class_goldens(ops, dev, golden_full, tag):
+    """3-conv WakewordModel against outputs of the reference's own class (wakeword_training_script.py:141-184)."""
+    sd = pkg.synth.make_state_dict("full", seed=1234)
+    packed = torch.from_numpy(ops.pack_state_dict(sd)).to(dev)
+    x = torch.from_numpy(golden_full["x" + tag]).to(dev)
+    pooled = ops.cnn_pool(x, packed, 3).cpu().numpy()
+    logits = ops.cnn_lstm_forward(x, packed, 3).cpu().numpy()
+    assert np.abs(pooled - golden_full["pooled" + tag]).max() <= 1e-4
+    assert np.abs(logits - golden_full["logits" + tag]).max() <= LOGIT_TOL
+    head = ops.lstm_fc(torch.from_numpy(golden_full["pooled" + tag]).to(dev), packed, 3).cpu().numpy()
+    assert np.abs(head - golden_full["logits" + tag]).max() <= 1e-5
+
+
 _ORACLE_CACHE = {}
 
 

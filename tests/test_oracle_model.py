@@ -50,9 +50,21 @@ def test_logits_do_not_depend_on_weight_hh_or_forget_gate(golden_simple, sd):
     assert np.abs(y - golden_simple["logits32"]).max() < 1e-6
 
 
+@pytest.mark.parametrize("tag", ["32", "31"])
+def test_full_model_closed_form_matches_reference_class_outputs(golden_full, tag):
+    # the fixture was produced by the reference's own WakewordModel class statement (ast-extracted, see make_golden.py)
+    sd = synth.make_state_dict("full", seed=1234)
+    x = golden_full["x" + tag]
+    assert np.abs(mo.pooled_features_np(x, sd) - golden_full["pooled" + tag]).max() < 2e-5
+    assert np.abs(mo.forward_np(x, sd) - golden_full["logits" + tag]).max() < 2e-6
+    m = mo.torch_module_from_state_dict(sd)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x)).numpy()
+    assert np.abs(y - golden_full["logits" + tag]).max() < 1e-6
+
+
 def test_full_model_closed_form_vs_torch_layers():
-    # WakewordModel (3 convs) cannot be imported from the reference (librosa/soundfile/seaborn at
-    # top level): pin the closed form against the same torch constructors instead.
+    # a second weight set / input range: the closed form against the same torch constructors
     sd = synth.make_state_dict("full", seed=99)
     assert sum(v.size for v in sd.values()) == 1014786           # model_architecture.txt:10
     x = synth.normal(5, 2 * 80 * 32).astype(np.float32).reshape(2, 1, 80, 32) * 20 - 40
