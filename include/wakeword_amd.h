@@ -68,7 +68,9 @@ WW_API int ww_init(void);
 /* Device facts used by bench.py for the roofline denominator: number of CUs, max clock (kHz). */
 WW_API int ww_device_info(int* n_cu, int* clock_khz, char* name, int name_len);
 /* Health check (synchronises the device): how many bounded in-kernel waits of the conv kernel's producer/consumer
- * protocol have expired since the library was loaded.  Always 0 unless the protocol is broken; negative = error code. */
+ * protocol have expired since the library was loaded.  Always 0 unless the protocol is broken; negative = error code.
+ * A workgroup whose wait expired overwrites every output it produced with NaN before it exits, so a broken launch
+ * cannot be consumed silently even without this call. */
 WW_API int ww_sync_timeouts(void);
 
 /* Arithmetic of the implicit GEMMs (conv1/conv2/conv3 and the LSTM gate GEMMs: all but ~1 % of the model's flops);
@@ -77,7 +79,9 @@ WW_API int ww_sync_timeouts(void);
  *   WW_CONV_MATH_F16X3  each fp32 operand carried as two f16 halves (22 significant bits), every product block as
  *                       three f16 MFMAs (v_mfma_f32_16x16x32_f16) with fp32 accumulation: ~2^-21 relative error per
  *                       product (PyTorch's own default for convolutions on the reference's GPU is TF32, 2^-11), 3/16
- *                       of the matrix-core cycles.  Requires activations < 65504. */
+ *                       of the matrix-core cycles.  Holds for any finite weights and inputs: weights carry a
+ *                       power-of-two scale per output channel, inputs and activations one exponent per clip chosen
+ *                       from the clip's max |x| and the layers' l1 bounds, so no f16 half overflows or goes subnormal. */
 #define WW_CONV_MATH_F32 0
 #define WW_CONV_MATH_F16X3 1
 WW_API int ww_set_conv_math(int mode);
@@ -149,7 +153,7 @@ WW_API int ww_kaiser_best_host(float* out_host);
  * (:78-83) and AudioProcessor.audio_to_mel (:85-101) =
  * librosa.feature.melspectrogram + librosa.power_to_db(ref=np.max), batched.
  *   pcm_dev      [n_clips] rows of `clip_len` valid samples, row i at pcm_dev + i*clip_stride
- *                (floats; 16-byte aligned base, clip_stride % 4 == 0, 0 < clip_len <= 16000;
+ *                (floats; 16-byte aligned base, clip_stride % 4 == 0 -- ignored for a single clip --, 0 < clip_len <= 16000;
  *                shorter rows are right-zero-padded like pad_or_truncate does)
  *   normalize    != 0: divide the clip by max|x| first (process_audio_file order, :131-133);
  *                a silent clip then yields NaN, as the reference does

@@ -85,44 +85,58 @@ def test_packed_weight_image_layout(arch):
             assert np.array_equal(b[:, g, :].reshape(-1), bias[rows])
     assert np.array_equal(take(512), sd["fc.weight"].reshape(-1))
     assert np.array_equal(take(4)[:2], sd["fc.bias"])
-    # split-precision images: w * 2^S = hi + lo (two f16 halves), good to ~2^-21 of the layer's largest weight
+    # split-precision images: every OUTPUT CHANNEL (row) carries its own power-of-two scale, w * 2^S[row] = hi + lo (two f16
+    # halves) with the row's largest |w'| in [2^12, 2^13): good to 2^-21 of the ROW's largest weight
+    def row_exps(descale, wrows):
+        S = -np.round(np.log2(descale.astype(np.float64))).astype(int)
+        assert np.array_equal(descale, (2.0 ** -S).astype(np.float32))                 # exact powers of two
+        m = np.abs(wrows).max(axis=1) * 2.0 ** S
+        assert np.all((m >= 2.0 ** 12) & (m < 2.0 ** 13))
+        return S
     w2 = sd["conv2.weight"].astype(np.float64)
-    descale = float(take(4)[0])
-    S = -int(round(np.log2(descale)))
-    assert 2.0 ** 12 <= np.abs(w2).max() * 2.0 ** S < 2.0 ** 13
+    S2 = row_exps(take(64), w2.reshape(64, -1))
     if n_conv == 3:
         w3 = sd["conv3.weight"].astype(np.float64)
         h3 = take(8 * 18 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(8, 18, 2, 64, 8)   # [nt16][ks][hi/lo][lane][j]
-        S3 = -int(round(np.log2(float(take(4)[0]))))
+        S3 = row_exps(take(128), w3.reshape(128, -1))
         nt3, cb3, dx3, dy3, lane3, j3 = np.meshgrid(np.arange(8), np.arange(2), np.arange(3), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
-        want3 = w3[16 * nt3 + (lane3 & 15), 32 * cb3 + 8 * (lane3 >> 4) + j3, dy3, dx3] * 2.0 ** S3     # ks = (cb*3 + dx)*3 + dy
-        assert np.abs((h3[:, :, 0] + h3[:, :, 1]).reshape(8, 2, 3, 3, 64, 8) - want3).max() <= np.abs(want3).max() * 2.0 ** -21
-    c1 = take(2 * 64 * 4).view(np.float16).astype(np.float64).reshape(2, 64, 8)                      # conv1 A operand: taps + bias tap
+        co3 = 16 * nt3 + (lane3 & 15)
+        want3 = w3[co3, 32 * cb3 + 8 * (lane3 >> 4) + j3, dy3, dx3] * 2.0 ** S3[co3]                   # ks = (cb*3 + dx)*3 + dy
+        assert np.abs((h3[:, :, 0] + h3[:, :, 1]).reshape(8, 2, 3, 3, 64, 8) - want3).max() <= 2.0 ** 13 * 2.0 ** -21
+    c1 = take(2 * 64 * 4).view(np.float16).astype(np.float64).reshape(2, 64, 8)                      # conv1 A operand: 9 taps, 7 zeros
+    hs1 = take(4)
+    S1 = int(row_exps(hs1[:1], sd["conv1.weight"].astype(np.float64).reshape(1, -1))[0])             # one scale for the tensor
     lane, j = np.meshgrid(np.arange(64), np.arange(8), indexing="ij")
     k = 8 * (lane >> 5) + j
-    w1b = np.concatenate([sd["conv1.weight"].reshape(32, 9), sd["conv1.bias"][:, None], np.zeros((32, 6), np.float32)], 1).astype(np.float64)
+    w1z = np.concatenate([sd["conv1.weight"].reshape(32, 9), np.zeros((32, 7), np.float32)], 1).astype(np.float64) * 2.0 ** S1
     mrow = lane & 31
-    assert np.abs((c1[0] + c1[1]) - w1b[(mrow & 3) + 4 * (mrow >> 3) + 16 * ((mrow >> 2) & 1), k]).max() <= 2.0 ** -22
+    assert np.abs((c1[0] + c1[1]) - w1z[(mrow & 3) + 4 * (mrow >> 3) + 16 * ((mrow >> 2) & 1), k]).max() <= 2.0 ** 13 * 2.0 ** -21
     h16 = take(4 * 9 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(4, 9, 2, 64, 8)       # [nt16][ks = dx*3+dy][hi/lo][lane][j]
     nt, dx, dy, lane, j = np.meshgrid(np.arange(4), np.arange(3), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
-    want16 = w2[16 * nt + (lane & 15), 8 * (lane >> 4) + j, dy, dx] * 2.0 ** S
-    assert np.abs((h16[:, :, 0] + h16[:, :, 1]).reshape(4, 3, 3, 64, 8) - want16).max() <= np.abs(want16).max() * 2.0 ** -21
+    co = 16 * nt + (lane & 15)
+    want16 = w2[co, 8 * (lane >> 4) + j, dy, dx] * 2.0 ** S2[co]
+    assert np.abs((h16[:, :, 0] + h16[:, :, 1]).reshape(4, 3, 3, 64, 8) - want16).max() <= 2.0 ** 13 * 2.0 ** -21
     # LSTM W_ih split for the 16x16x32 f16 MFMA: [K/32][48 ntile][hi/lo][64 lanes][8]; column c = 16 nt + lane%16 in the
-    # same (hb, gate, u) order as the f32 image, k = 32 kb + 8 (lane//16) + j
+    # same (hb, gate, u) order as the f32 image, k = 32 kb + 8 (lane//16) + j; one scale per packed column
     Ks = [64 if arch == "simple" else 128, 256]
     lh = [take(K // 32 * 48 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(K // 32, 48, 2, 64, 8) for K in Ks]
-    hs = take(4)
+    hs = take(2 * 768).reshape(2, 768)
     goff = np.array([0, 512, 768])
+    cols = np.arange(768)
+    col_row = goff[(cols % 96) // 32] + 32 * (cols // 96) + cols % 32
     for layer, K in enumerate(Ks):
         w_ih = sd[f"lstm.weight_ih_l{layer}"].astype(np.float64)
-        S = -int(round(np.log2(float(hs[layer]))))
-        live = w_ih[np.concatenate([np.arange(0, 256), np.arange(512, 1024)])]
-        assert 2.0 ** 12 <= np.abs(live).max() * 2.0 ** S < 2.0 ** 13
+        S = row_exps(hs[layer], w_ih[col_row])
         kb, nt, lane, j = np.meshgrid(np.arange(K // 32), np.arange(48), np.arange(64), np.arange(8), indexing="ij")
         c = 16 * nt + (lane & 15)
-        row = goff[(c % 96) // 32] + 32 * (c // 96) + c % 32
-        want = w_ih[row, 32 * kb + 8 * (lane >> 4) + j] * 2.0 ** S
-        assert np.abs((lh[layer][:, :, 0] + lh[layer][:, :, 1]) - want).max() <= np.abs(want).max() * 2.0 ** -21
+        want = w_ih[col_row[c], 32 * kb + 8 * (lane >> 4) + j] * 2.0 ** S[c]
+        assert np.abs((lh[layer][:, :, 0] + lh[layer][:, :, 1]) - want).max() <= 2.0 ** 13 * 2.0 ** -21
+    # range bounds for the per-clip activation exponents: |conv_l out| <= max|in| * l1[l] + max|b_l|
+    rng = take(8)
+    for li, (l1, bm) in enumerate([(rng[0], rng[1]), (rng[2], rng[3])], start=1):
+        w = sd[f"conv{li}.weight"].astype(np.float64)
+        true_l1 = np.abs(w).reshape(w.shape[0], -1).sum(axis=1).max()
+        assert true_l1 <= l1 <= true_l1 * 1.0001 and bm == np.abs(sd[f"conv{li}.bias"]).max()
     assert o == p.size
 
 
@@ -157,7 +171,8 @@ def test_resampler_taps_match_scipy_design():
 
 def test_size_queries_do_not_need_a_gpu():
     assert nat.lib.ww_workspace_bytes(4096, 2) >= 4096 * (2560 + 64) * 4
-    assert nat.lib.ww_cnn_scratch_bytes(16, 2) == 0 and nat.lib.ww_cnn_scratch_bytes(16, 3) == 16 * 80 * 64 * 32 * 4
+    # relu(conv2) records of the 3-conv model + one per-clip scale float (256-byte aligned block)
+    assert nat.lib.ww_cnn_scratch_bytes(16, 2) == 0 and nat.lib.ww_cnn_scratch_bytes(16, 3) == 16 * 80 * 64 * 32 * 4 + 256
 
 
 @pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")

@@ -100,7 +100,8 @@ static int check_pcm(const float* pcm, int64_t n_clips, int64_t clip_stride, int
         return fail(WW_EINVAL, "clip_len %lld: expected 1..%d samples (longer clips are cropped by the host, "
                     "pad_or_truncate wakeword_training_script.py:78-83)", (long long)clip_len, kClip);
     if (clip_stride < clip_len && n_clips > 1) return fail(WW_EINVAL, "clip_stride %lld < clip_len %lld", (long long)clip_stride, (long long)clip_len);
-    if ((reinterpret_cast<uintptr_t>(pcm) & 15) || (clip_stride & 3))
+    // a single clip has no second row: its stride is never used (any clip_len, e.g. 15999, is fine)
+    if ((reinterpret_cast<uintptr_t>(pcm) & 15) || (n_clips > 1 && (clip_stride & 3)))
         return fail(WW_EINVAL, "pcm must be 16-byte aligned with clip_stride %% 4 == 0 (got %p, %lld)", (const void*)pcm, (long long)clip_stride);
     return WW_OK;
 }

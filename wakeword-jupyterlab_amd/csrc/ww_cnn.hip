@@ -23,6 +23,7 @@
 // Algorithmic flops per clip (T = 32): conv1 1,474,560 + conv2 94,371,840 [+ conv3 377,487,360].
 // Diagnostic build: -DWW_STAMPS adds s_memtime phase stamps (never in the shipped library).
 #include <cstdlib>
+#include <mutex>
 
 #include "ww_internal.h"
 
@@ -217,13 +218,22 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kPos16 = 160;
 constexpr int kH16Row = kRS * kPos16;
 constexpr int kH16Act = kARows * kH16Row;                   // 54,400 B per buffer
-constexpr int kZeroRowsHalfs = (kH + 2) * 36 + 3 * 36;            // three zero rows whose lo twin (+ one plane) is zero too
-constexpr int kC2h16Lds = 2 * kH16Act + (4 * ((kH + 2) * 36) + kZeroRowsHalfs) * 2 + 8 * 16 * 4;
+constexpr int kC2h16Lds = 2 * kH16Act + 4 * ((kH + 2) * 36) * 2 + 8 * 16 * 4;
 
 // conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
-//   D[ci][x] = sum_k W1[ci][k] * P[k][x],  k = 3*dy + dx (9 taps), k = 9: bias * 1.0, split precision as conv2.
+//   D[ci][x] = sum_k W1'[ci][k] * P'[k][x],  k = 3*dy + dx (9 taps; the other 7 of the 16 are zero), split precision as conv2.
 // The log-mel tile is kept as two f16 planes (hi, lo) so the patch operand needs no conversions.  The result lands
-// with the column on the lane and 16 channels in registers: 2*relu, split, 8-byte stores into the position records.
+// with the column on the lane and 16 channels in registers: descale, 2*relu, split, 8-byte stores
+// into the position records.  The bias enters as the MFMA's C operand (16 VGPRs per producer lane, rebuilt per clip).
+//
+// Dynamic range (so that the split precision holds for ANY finite weights and inputs, not only log-mel in [-80, 0] dB):
+//   weights   conv1: one power-of-two scale 2^S1 for the tensor (a wave-uniform descale); conv2 / conv3 / LSTM: every
+//             output channel has its own (a per-lane constant of the D layout) -- host, ww_tables.cpp;
+//   inputs    P' = x * 2^-e with ONE exponent e per clip, chosen from the clip's max |x| so that max |P'| is in [2^14, 2^15);
+//   outputs   the tile holds 2 relu(conv1) * 2^-a with one exponent a per clip chosen from the bound
+//             max|x| * max_c sum_k |w1[c][k]| + max |b1|, so that it stays below 2^15 (f16 overflows at 65504) and
+//             small activations keep both halves normal;  conv2's descale carries 2^a.
+// Powers of two commute with fp32 rounding, so for log-mel inputs the result is what the unscaled arithmetic gives.
 constexpr int kMelHRS = 36;                              // f16 plane row stride (columns -1..34)
 constexpr int kMelHPlane = (kH + 2) * kMelHRS;           // halfs per plane
 // One row of conv1 on the matrix cores, split into its three stages so that a producer can run the stages of its
@@ -233,11 +243,19 @@ struct Conv1Row {
     f32x16 acc;
 };
 
-// Patch operand of a row: lane (x, h) needs B[k = 8h + j][x], j = 0..7 -- taps 0..7 for the lower half-wave; tap 8, the
-// bias tap (1.0) and six zeros for the upper one.  Column 34 of every row of the hi plane holds 1.0 and column 35 (and
-// both columns of the lo plane) 0, so the upper half-wave differs from the lower one only in its ADDRESSES: eight
-// per-lane offsets, computed once, replace 32 selects per row.  (ds_read_u16_d16 pairs would also save the packing, but
-// with SRAM ECC on a d16 load clears the other half of its register.)
+// The per-clip constants of a producer lane: the accumulator of channel c = 16h + j starts at binit[j] = b1[c] * 2^(S1 - e)
+// (the bias in the accumulator's scale) and the finished row is multiplied by sc = 2^(e - a - S1) (wave-uniform).
+struct Conv1Scale { f32x16 binit; float sc; };
+
+// floor(log2 |v|) of a normal float (-127 for zero / subnormals, 128 for inf / NaN)
+__device__ __forceinline__ int exp_of(float v) { return int((__float_as_uint(v) >> 23) & 0xffu) - 127; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float(uint32_t(127 + e) << 23); }   // -126 <= e <= 127
+
+// Patch operand of a row: lane (x, h) needs B[k = 8h + j][x], j = 0..7 -- taps 0..7 for the lower half-wave; tap 8 and
+// seven zeros for the upper one.  Columns 34 and 35 of every plane row are zero, so the upper half-wave differs from the
+// lower one only in its ADDRESSES: eight per-lane offsets, computed once, replace 32 selects per row.  (ds_read_u16_d16
+// pairs would also save the packing, but with SRAM ECC on a d16 load clears the other half of its register.)
 struct GatherLanes { int o[8]; };      // offsets in halfs relative to the first plane row of the patch, column 0
 
 __device__ __forceinline__ GatherLanes gather_lanes(int x, int h) {
@@ -245,19 +263,14 @@ __device__ __forceinline__ GatherLanes gather_lanes(int x, int h) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int lower = (j / 3) * kMelHRS + j % 3 + x;                             // tile coords: row y+dy, col x+dx
-        const int upper = j == 0 ? 2 * kMelHRS + 2 + x : (j == 1 ? 34 : 35);
+        const int upper = j == 0 ? 2 * kMelHRS + 2 + x : 34 + (j & 1);
         g.o[j] = h ? upper : lower;
     }
     return g;
 }
 
-// Rows outside the image (conv2's zero padding) and columns beyond `width` must come out as exact zeros: their lanes
-// read an all-zero patch -- bias tap included -- from `zrow` (three zero rows whose lo twin is zero too): ONE address
-// select per row instead of a select per output value.
-__device__ __forceinline__ void conv1_row_gather(Conv1Row& r, const _Float16* __restrict__ mh, const _Float16* __restrict__ zrow,
-                                                 const GatherLanes& gl, int y, bool col_ok) {
-    const bool live = y >= 0 && y < kH && col_ok;
-    const _Float16* __restrict__ row = live ? mh + y * kMelHRS : zrow;
+__device__ __forceinline__ void conv1_row_gather(Conv1Row& r, const _Float16* __restrict__ mh, const GatherLanes& gl, int y) {
+    const _Float16* __restrict__ row = mh + y * kMelHRS;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         r.ph[j] = row[gl.o[j]];
@@ -265,10 +278,8 @@ __device__ __forceinline__ void conv1_row_gather(Conv1Row& r, const _Float16* __
     }
 }
 
-__device__ __forceinline__ void conv1_row_mfma(Conv1Row& r, half8 a1h, half8 a1l) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) r.acc[j] = 0.f;
-    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, r.ph, r.acc, 0, 0, 0);
+__device__ __forceinline__ void conv1_row_mfma(Conv1Row& r, half8 a1h, half8 a1l, const Conv1Scale& cs) {
+    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, r.ph, cs.binit, 0, 0, 0);
     r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, r.pl, r.acc, 0, 0, 0);
     r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, r.ph, r.acc, 0, 0, 0);
 }
@@ -286,16 +297,18 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     lo = __builtin_bit_cast(uint32_t, l);
 }
 
+
 // D: lane&31 = column x; the weight rows are permuted on the host so that register j holds channel 16*h + j:
-// 2*relu, hi/lo split, and the lane's 16 contiguous channels go out as two 16-byte stores per half.
-__device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restrict__ rec) {
+// descale, 2*relu, hi/lo split, and the lane's 16 contiguous channels go out as two 16-byte stores per half.
+__device__ __forceinline__ void conv1_row_store(const Conv1Row& r, const Conv1Scale& cs, char* __restrict__ rec) {
 #pragma unroll
     for (int g8 = 0; g8 < 2; ++g8) {
         u32x4 vh, vl;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
+            const int j = 8 * g8 + 2 * d;
             uint32_t hh, ll;       // 2*relu: the factor is folded into conv2's descale
-            split2(relu2(r.acc[8 * g8 + 2 * d]), relu2(r.acc[8 * g8 + 2 * d + 1]), hh, ll);
+            split2(relu2(r.acc[j] * cs.sc), relu2(r.acc[j + 1] * cs.sc), hh, ll);
             vh[d] = hh;
             vl[d] = ll;
         }
@@ -303,27 +316,66 @@ __device__ __forceinline__ void conv1_row_store(const Conv1Row& r, char* __restr
         *reinterpret_cast<u32x4*>(rec + 64 + g8 * 16) = vl;
     }
 }
+__device__ __forceinline__ void conv1_row_zero(char* __restrict__ rec) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int g8 = 0; g8 < 2; ++g8) {
+        *reinterpret_cast<u32x4*>(rec + g8 * 16) = z;
+        *reinterpret_cast<u32x4*>(rec + 64 + g8 * 16) = z;
+    }
+}
 
 // A producer runs tile rows qa and (if SECOND) qa + 4 of the band side by side.  mh: the clip's hi plane.
+// Rows outside the image are conv2's zero padding: zero records (wave-uniform branch; two rows per clip).  Columns beyond
+// `width` are never stored: their records keep the zeros of the kernel's initial fill.
 template <int POS, bool SECOND>
-__device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const _Float16* __restrict__ zrow,
-                                                const GatherLanes& gl, char* __restrict__ act, half8 a1h, half8 a1l, int y0,
-                                                int width, int qa, int lane) {
+__device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh, const GatherLanes& gl, char* __restrict__ act,
+                                                half8 a1h, half8 a1l, const Conv1Scale& cs, int y0, int width, int qa, int lane) {
     const int x = lane & 31, h = lane >> 5;
     const bool col_ok = x < width;
-    Conv1Row r0, r1;
-    conv1_row_gather(r0, mh, zrow, gl, y0 - 1 + qa, col_ok);
-    if (SECOND) conv1_row_gather(r1, mh, zrow, gl, y0 - 1 + qa + 4, col_ok);
-    conv1_row_mfma(r0, a1h, a1l);
-    if (SECOND) conv1_row_mfma(r1, a1h, a1l);
+    const int ya = y0 - 1 + qa, yb = ya + 4;
+    const bool va = ya >= 0 && ya < kH, vb = yb >= 0 && yb < kH;
     char* rec = act + (x + 1) * POS + h * 32;                          // this lane's 16 channels 16h..16h+15
-    conv1_row_store(r0, rec + qa * kRS * POS);
-    if (SECOND) conv1_row_store(r1, rec + (qa + 4) * kRS * POS);
+    char* reca = rec + qa * kRS * POS;
+    char* recb = rec + (qa + 4) * kRS * POS;
+    if (va && (!SECOND || vb)) {
+        Conv1Row r0, r1;
+        conv1_row_gather(r0, mh, gl, ya);
+        if (SECOND) conv1_row_gather(r1, mh, gl, yb);
+        conv1_row_mfma(r0, a1h, a1l, cs);
+        if (SECOND) conv1_row_mfma(r1, a1h, a1l, cs);
+        if (col_ok) {
+            conv1_row_store(r0, cs, reca);
+            if (SECOND) conv1_row_store(r1, cs, recb);
+        }
+        return;
+    }
+    // a row above or below the image is involved (first tile row of band 0, last of band 9): one row at a time
+    if (va) {
+        Conv1Row r0;
+        conv1_row_gather(r0, mh, gl, ya);
+        conv1_row_mfma(r0, a1h, a1l, cs);
+        if (col_ok) conv1_row_store(r0, cs, reca);
+    } else {
+        conv1_row_zero(reca);
+    }
+    if (SECOND) {
+        if (vb) {
+            Conv1Row r1;
+            conv1_row_gather(r1, mh, gl, yb);
+            conv1_row_mfma(r1, a1h, a1l, cs);
+            if (col_ok) conv1_row_store(r1, cs, recb);
+        } else {
+            conv1_row_zero(recb);
+        }
+    }
 }
 
 // Workgroup-local progress counters in LDS (monotonic).  signal = release add by one wave; wait = acquire poll.  The
-// poll is bounded (~0.2 s): a protocol bug then cannot hang the GPU; it is counted in g_sync_timeouts, which the host
-// reads with ww_sync_timeouts() (the GPU tests assert that it stays 0).
+// poll is bounded (~0.2 s): a protocol bug then cannot hang the GPU.  An expired wait is FATAL for the workgroup's
+// results: it raises the workgroup's `bad` word in LDS, and before the workgroup exits every output of every clip it
+// processed is overwritten with NaN (a wave that ran ahead on stale data cannot be consumed silently).  It is also
+// counted in g_sync_timeouts, which the host reads with ww_sync_timeouts() (the GPU tests assert that it stays 0).
 __device__ unsigned int g_sync_timeouts;
 
 // The fences are executed by EVERY lane (the counter itself only by lane 0 / read by all): release and acquire order the
@@ -332,9 +384,12 @@ __device__ __forceinline__ void flag_signal(uint32_t* f) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target) {
+#ifndef WW_FLAG_SPINS
+#define WW_FLAG_SPINS (1 << 22)
+#endif
+__device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target, uint32_t* bad) {
 #pragma unroll 1
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+    for (int spin = 0; spin < WW_FLAG_SPINS; ++spin) {
         if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             return;
@@ -342,7 +397,10 @@ __device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target) {
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sync_timeouts, 1u);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_sync_timeouts, 1u);
+        __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 
 #ifdef WW_STAMPS
@@ -353,18 +411,21 @@ __device__ unsigned long long g_cnn_stamps[16];
 #define CSTAMP(i) do {} while (0)
 #endif
 
-// POOL: out = pooled [n][64].   !POOL (3-conv model): out = relu(conv2) already split for conv3, as f16
-// [n][80 rows][32 columns][64 ci hi | 64 ci lo] (256 bytes per position, zero beyond `width`).
+// POOL: out = pooled [n][64].   !POOL (3-conv model): out = relu(conv2) * 2^-a2 already split for conv3, as f16
+// [n][80 rows][32 columns][64 ci hi | 64 ci lo] (256 bytes per position, zero beyond `width`), and apow2[clip] = 2^a2
+// (one float per clip behind the records; a2 from the bound on |conv2 out|, see the conv1 notes above).
+// rng: [l1 bound of conv1, max |b1|, l1 bound of conv2, max |b2|] (ww_tables.cpp).
 template <bool POOL>
 __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict__ mel, int n, int width,
-                                                         const u32x4* __restrict__ w1H,
+                                                         const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
+                                                         const float* __restrict__ b1,
                                                          const u32x4* __restrict__ wH, const float* __restrict__ hs,
-                                                         const float* __restrict__ b2, float* __restrict__ out) {
+                                                         const float* __restrict__ b2, const float* __restrict__ rng,
+                                                         float* __restrict__ out, float* __restrict__ apow2) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* act0 = ldsb;
     _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + 2 * kH16Act);       // 2 clips x (hi plane, lo plane) of [82][36] f16
-    const _Float16* zrow = melh0 + 4 * kMelHPlane;                           // zero patch rows (never written)
-    float* red = reinterpret_cast<float*>(melh0 + 4 * kMelHPlane + kZeroRowsHalfs);   // [8 consumer waves][16]
+    float* red = reinterpret_cast<float*>(melh0 + 4 * kMelHPlane);           // [8 consumer waves][16]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -382,7 +443,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             bl[ks] = __builtin_bit_cast(half8, wH[((nt * 9 + ks) * 2 + 1) * 64 + lane]);
         }
         bias = b2[16 * nt + pi];
-        descale = 0.5f * hs[0];                  // conv1 activations are stored as 2*relu(.)
+        descale = 0.5f * hs[16 * nt + pi];       // this lane's output channel; conv1 activations are stored as 2*relu(.)
     }
     half8 a1h = {}, a1l = {};
     const GatherLanes glanes = gather_lanes(lane & 31, lane >> 5);
@@ -396,32 +457,69 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         // the consumers wait a third of the time at the band barrier.
         __builtin_amdgcn_s_setprio(3);
     }
-    // progress counters: tiles produced x 4 producer waves, bands consumed x 8 consumer waves, mel planes loaded x 4
-    __shared__ uint32_t prod_done, cons_done[2], mel_done;
-    if (tid == 0) { prod_done = 0u; cons_done[0] = 0u; cons_done[1] = 0u; mel_done = 0u; }
-    // zero fill; column 34 of every row of the two hi planes is the constant 1.0 (f16 0x3C00) of the bias tap
-    for (int i = tid; i < kC2h16Lds / 4; i += 768) {
-        const int w = i - 2 * kH16Act / 4;               // dword index inside the four planes (hi, lo, hi, lo)
-        const bool one = w >= 0 && w < 4 * (kMelHPlane / 2) && ((w / (kMelHPlane / 2)) & 1) == 0 && (w % (kMelHRS / 2)) == 17;
-        reinterpret_cast<uint32_t*>(ldsb)[i] = one ? 0x00003C00u : 0u;
-    }
+    // progress counters: tiles produced x 4 producer waves, bands consumed x 8 consumer waves, mel planes loaded x 4,
+    // per-wave input maxima published x 4
+    __shared__ uint32_t prod_done, cons_done[2], mel_done, xmax_done, wg_bad;
+    __shared__ float xmaxw[2][4];        // [clip parity][producer wave]: max |x| over the wave's share of the clip
+    __shared__ float clip_par[2][2];     // [clip parity]: 2^a (conv1 activation exponent), bound on |conv1 out|
+    if (tid == 0) { prod_done = 0u; cons_done[0] = 0u; cons_done[1] = 0u; mel_done = 0u; xmax_done = 0u; wg_bad = 0u; }
+    for (int i = tid; i < kC2h16Lds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;   // halos / dead columns stay zero
     __syncthreads();
 
     const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
     const int steps = my_clips * (kH / kBand);
     const float half_inv_area = 0.5f / float(kH * width);
 
-    auto load_mel = [&](int k) {     // log-mel image -> two f16 planes (hi, lo) with a zero halo
+    const float rng_l1 = rng[0], rng_b1 = rng[1];
+    // Model input of clip k -> two f16 planes (hi, lo) of x * 2^-e with a zero halo; e from the clip's max |x| (a NaN is
+    // ignored by the max and propagates through the arithmetic; an infinity scales to an infinity).  The four producer
+    // waves publish their maxima through LDS and meet on a counter; slot reuse (clip k + 2) is safe because the producers
+    // advance tile by tile.  Returns the clip's exponents: e (input), a (conv1 activations).
+    auto load_mel = [&](int k, int& e_out, int& a_out) {
         const float* __restrict__ src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kH * width;
         _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
-        _Float16* pl = ph + kMelHPlane;
-        for (int i = ptid; i < kH * width; i += 256) {
-            const int y = i / width, xx = i - y * width;
-            const float v = src[i];
-            const _Float16 hi = static_cast<_Float16>(v);
-            ph[(y + 1) * kMelHRS + xx + 1] = hi;
-            pl[(y + 1) * kMelHRS + xx + 1] = static_cast<_Float16>(v - static_cast<float>(hi));
+        // thread -> (column xx, rows y0 + 8 t): no division for any width; for width 32 consecutive threads read consecutive floats
+        const int xx = ptid & 31, y0 = ptid >> 5;
+        const bool col_live = xx < width;
+        const float* __restrict__ sp = src + y0 * width + xx;
+        float v[10];
+        float mx = 0.f;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            v[t] = col_live ? sp[8 * t * width] : 0.f;
+            mx = fmaxf(mx, __builtin_fabsf(v[t]));
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) xmaxw[k & 1][wave - 8] = mx;
+        flag_signal(&xmax_done);
+        flag_wait(&xmax_done, 4u * unsigned(k + 1), &wg_bad);
+        mx = fmaxf(fmaxf(xmaxw[k & 1][0], xmaxw[k & 1][1]), fmaxf(xmaxw[k & 1][2], xmaxw[k & 1][3]));
+        const int e = clampi(exp_of(mx) - 14, -100, 113);
+        const float bound1 = fmaf(mx, rng_l1, rng_b1);
+        const int a = clampi(exp_of(bound1) - 13, -100, 100);
+        if (tid == 512) { clip_par[k & 1][0] = pow2i(a); clip_par[k & 1][1] = bound1; }
+        const float down = pow2i(-e);
+        if (col_live) {
+            _Float16* dh = ph + (y0 + 1) * kMelHRS + xx + 1;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float vv = v[t] * down;
+                const _Float16 hi = static_cast<_Float16>(vv);
+                dh[8 * t * kMelHRS] = hi;
+                dh[8 * t * kMelHRS + kMelHPlane] = static_cast<_Float16>(vv - static_cast<float>(hi));
+            }
+        }
+        e_out = e;
+        a_out = a;
+    };
+    Conv1Scale cs;
+    const int s1_exp = -exp_of(hs1[0]);               // hs1[0] = 2^-S1
+    auto set_conv1_scale = [&](int e, int a) {       // channel 16h + j of this producer lane
+        const int c0 = 16 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cs.binit[j] = ldexpf(b1[c0 + j], s1_exp - e);
+        cs.sc = ldexpf(1.0f, e - a - s1_exp);
     };
     // conv1 of step g (clip g / 10, band g % 10) into tile g & 1.  Band 0 computes all ten rows (row 0 is the zero
     // padding above the image); for the other bands tile rows 0 and 1 (image rows 8b - 1, 8b) are the previous band's
@@ -433,8 +531,8 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
         char* tile = act0 + (g & 1) * kH16Act;
         const int pw = wave - 8;
         if (band == 0) {
-            conv1_rows_mfma<kPos16, true>(plane, zrow, glanes, tile, a1h, a1l, 0, width, 2 + pw, lane);
-            if (pw < 2) conv1_rows_mfma<kPos16, false>(plane, zrow, glanes, tile, a1h, a1l, 0, width, pw, lane);
+            conv1_rows_mfma<kPos16, true>(plane, glanes, tile, a1h, a1l, cs, 0, width, 2 + pw, lane);
+            if (pw < 2) conv1_rows_mfma<kPos16, false>(plane, glanes, tile, a1h, a1l, cs, 0, width, pw, lane);
             return;
         }
         // halo rows: read first, written last -- the LDS round trip hides under the conv1 work
@@ -445,7 +543,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
             const int c = ptid + 256 * i;                              // chunk: position c >> 3 (2 rows x 34), 16-byte part c & 7
             if (c < 2 * kRS * 8) halo[i] = *reinterpret_cast<const u32x4*>(prev + (c >> 3) * kPos16 + (c & 7) * 16);
         }
-        conv1_rows_mfma<kPos16, true>(plane, zrow, glanes, tile, a1h, a1l, band * kBand, width, 2 + pw, lane);
+        conv1_rows_mfma<kPos16, true>(plane, glanes, tile, a1h, a1l, cs, band * kBand, width, 2 + pw, lane);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int c = ptid + 256 * i;
@@ -476,30 +574,46 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     // 8 (g - 1) with a reader of the buffer still busy; a wave cannot be two bands (one parity) ahead, because the tile it
     // would need is gated by exactly this wait.  The producers' counter is exact because they advance tile by tile.
     if (!consumer) {
-        if (steps > 0) { load_mel(0); flag_signal(&mel_done); }
+        int e_nx = 0, a_nx = 0;                       // exponents of the clip whose planes were loaded last
+        if (steps > 0) { load_mel(0, e_nx, a_nx); flag_signal(&mel_done); }
         for (int g = 0; g < steps; ++g) {
             const int k = g / (kH / kBand), band = g - k * (kH / kBand);
             CSTAMP(0);
-            flag_wait(&prod_done, 4u * unsigned(g));
-            if (band == 0) flag_wait(&mel_done, 4u * unsigned(k + 1));
-            if (g >= 2) flag_wait(&cons_done[g & 1], 8u * unsigned(g / 2));
+            flag_wait(&prod_done, 4u * unsigned(g), &wg_bad);
+            if (band == 0) {
+                flag_wait(&mel_done, 4u * unsigned(k + 1), &wg_bad);
+                set_conv1_scale(e_nx, a_nx);
+            }
+            if (g >= 2) flag_wait(&cons_done[g & 1], 8u * unsigned(g / 2), &wg_bad);
             CSTAMP(4);
             produce(g);
             flag_signal(&prod_done);
             if (band == 0 && k + 1 < my_clips) {       // planes (k + 1) & 1 were clip k - 1's, whose last tile is complete
-                load_mel(k + 1);
+                load_mel(k + 1, e_nx, a_nx);
                 flag_signal(&mel_done);
             }
             CSTAMP(3);
         }
     } else {
+    float dsc = descale, a2inv = 1.f;    // per clip: descale * 2^a;  !POOL: 2^-a2 for the stored relu(conv2)
     for (int g = 0; g < steps; ++g) {
         const int k = g / (kH / kBand), band = g - k * (kH / kBand);
         CSTAMP(0);
-        flag_wait(&prod_done, 4u * unsigned(g + 1));                   // tile g complete
+        flag_wait(&prod_done, 4u * unsigned(g + 1), &wg_bad);                   // tile g complete
+        if (band == 0) {
+            // the clip's exponents were published before its first tile; slot k & 1 is rewritten for clip k + 2 only after
+            // every consumer has finished band 8 of clip k, i.e. long after this read
+            dsc = descale * clip_par[k & 1][0];
+            if constexpr (!POOL) {
+                const float bound2 = fmaf(clip_par[k & 1][1], rng[2], rng[3]);
+                const int a2 = clampi(exp_of(bound2) - 14, -100, 100);
+                a2inv = pow2i(-a2);
+                if (tid == 0) apow2[int64_t(blockIdx.x) + int64_t(k) * gridDim.x] = pow2i(a2);
+            }
+        }
         if (POOL && band == 0 && g > 0 && wave == 0) {                // red[] of clip k - 1 complete (g is even)
-            flag_wait(&cons_done[0], 8u * unsigned(g / 2));
-            flag_wait(&cons_done[1], 8u * unsigned(g / 2));
+            flag_wait(&cons_done[0], 8u * unsigned(g / 2), &wg_bad);
+            flag_wait(&cons_done[1], 8u * unsigned(g / 2), &wg_bad);
         }
         CSTAMP(4);
         {
@@ -529,7 +643,7 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int xx = 16 * c + 4 * kq + j, y = band * kBand + rg * 4 + r;
-                            float v = 0.5f * relu2(fmaf(acc[r][c][j], descale, bias));
+                            float v = 0.5f * a2inv * relu2(fmaf(acc[r][c][j], dsc, bias));
                             v = xx < width ? v : 0.f;
                             const _Float16 hi = static_cast<_Float16>(v);
                             const int64_t rec = ((clip * kH + y) * kW + xx) * 128 + 16 * nt + pi;
@@ -540,13 +654,13 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) pool += relu2(fmaf(acc[r][c][j], descale, bias));
+                        for (int j = 0; j < 4; ++j) pool += relu2(fmaf(acc[r][c][j], dsc, bias));
                 } else {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float v = relu2(fmaf(acc[r][c][j], descale, bias));
+                            const float v = relu2(fmaf(acc[r][c][j], dsc, bias));
                             pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
                         }
                 }
@@ -591,9 +705,19 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
     }
     }
     if (POOL && consumer && wave == 0 && steps > 0) {
-        flag_wait(&cons_done[0], 8u * unsigned(steps / 2));       // steps = 10 x clips: even
-        flag_wait(&cons_done[1], 8u * unsigned(steps / 2));
+        flag_wait(&cons_done[0], 8u * unsigned(steps / 2), &wg_bad);       // steps = 10 x clips: even
+        flag_wait(&cons_done[1], 8u * unsigned(steps / 2), &wg_bad);
         write_pooled(my_clips - 1);
+    }
+    // an expired wait anywhere in this workgroup: poison everything it produced (pooled features, or the conv3 scale)
+    __syncthreads();
+    if (__hip_atomic_load(&wg_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+        const float nan = __uint_as_float(0x7fc00000u);
+        for (int k = 0; k < my_clips; ++k) {
+            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+            if constexpr (POOL) { if (tid < 64) out[clip * 64 + tid] = nan; }
+            else { if (tid == 0) apow2[clip] = nan; }
+        }
     }
 #ifdef WW_STAMPS
     if (lane == 0 && blockIdx.x == 7 && (wave == 1 || wave == 9))
@@ -700,8 +824,8 @@ constexpr int kT3Rows = 6;
 constexpr int kT3Bytes = kT3Rows * kRS * kRec3;              // 58,752
 constexpr int kC3hLds = 2 * kT3Bytes;
 
-__global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restrict__ in, int n, int width,
-                                                       const u32x4* __restrict__ wH, const float* __restrict__ hs,
+__global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restrict__ in, const float* __restrict__ apow2, int n,
+                                                       int width, const u32x4* __restrict__ wH, const float* __restrict__ hs,
                                                        const float* __restrict__ b3, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -715,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restric
         bl[ks] = __builtin_bit_cast(half8, wH[((nt * 18 + ks) * 2 + 1) * 64 + lane]);
     }
     const float bias = b3[16 * nt + pi];
-    const float descale = hs[0];
+    const float descale = hs[16 * nt + pi];          // this lane's output channel
     for (int i = tid; i < kC3hLds / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;
     __syncthreads();
 
@@ -745,9 +869,10 @@ __global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restric
 
     if (steps > 0) { fetch(0); stash(0); }
     __syncthreads();
-    float pool = 0.f;
+    float pool = 0.f, dsc = descale;
     for (int g = 0; g < steps; ++g) {
         const int k = g / bands, band = g - k * bands;
+        if (band == 0) dsc = descale * apow2[int64_t(blockIdx.x) + int64_t(k) * gridDim.x];   // the records hold relu(conv2) * 2^-a2
         if (g + 1 < steps) fetch(g + 1);
         const char* ap = ldsb + (g & 1) * kT3Bytes + pi * kRec3 + kq * 16;
         f32x4 acc[4][2];
@@ -791,7 +916,7 @@ __global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restric
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float v = relu2(fmaf(acc[r][c][j], descale, bias));
+                    const float v = relu2(fmaf(acc[r][c][j], dsc, bias));
                     pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
                 }
         if (band == bands - 1) {
@@ -810,13 +935,17 @@ int sync_timeouts(unsigned int* count) {
     return WW_OK;
 }
 
+// relu(conv2) of the 3-conv model: 655,360 bytes per clip in either arithmetic, + one float per clip (f16x3: 2^a2)
+static int64_t mid_bytes(int64_t n) { return n * int64_t(kH) * 64 * kW * int64_t(sizeof(float)); }
 int64_t cnn_scratch_bytes(int64_t n, int n_conv) {
-    return n_conv == 3 ? n * int64_t(kH) * 64 * kW * int64_t(sizeof(float)) : 0;
+    return n_conv == 3 ? mid_bytes(n) + ((n * int64_t(sizeof(float)) + 255) & ~int64_t(255)) : 0;
 }
 
 // > 64 KiB of dynamic LDS needs an opt-in per kernel, once per device
 static int opt_in_lds() {
+    static std::mutex mu;
     static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     WW_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
@@ -842,17 +971,20 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
         const u32x4* w1h = reinterpret_cast<const u32x4*>(packed + L.conv1_h);
         const u32x4* w2h = reinterpret_cast<const u32x4*>(packed + L.conv2_h16);
         if (n_conv == 2) {
-            hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width, w1h, w2h,
-                               packed + L.conv2_hs, packed + L.conv2_b, pooled);
+            hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width, w1h,
+                               packed + L.conv1_hs, packed + L.conv1_b, w2h, packed + L.conv2_hs, packed + L.conv2_b,
+                               packed + L.range, pooled, static_cast<float*>(nullptr));
             WW_HIP(hipGetLastError());
             return WW_OK;
         }
-        hipLaunchKernelGGL(cnn2h16_kernel<false>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width, w1h, w2h,
-                           packed + L.conv2_hs, packed + L.conv2_b, static_cast<float*>(scratch));
+        float* apow2 = reinterpret_cast<float*>(static_cast<char*>(scratch) + mid_bytes(n));
+        hipLaunchKernelGGL(cnn2h16_kernel<false>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width, w1h,
+                           packed + L.conv1_hs, packed + L.conv1_b, w2h, packed + L.conv2_hs, packed + L.conv2_b,
+                           packed + L.range, static_cast<float*>(scratch), apow2);
         WW_HIP(hipGetLastError());
         hipLaunchKernelGGL(cnn3h_kernel, dim3(grid1), dim3(512), kC3hLds, stream, static_cast<const _Float16*>(scratch),
-                           int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_h), packed + L.conv3_hs,
-                           packed + L.conv3_b, pooled);
+                           static_cast<const float*>(apow2), int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_h),
+                           packed + L.conv3_hs, packed + L.conv3_b, pooled);
         WW_HIP(hipGetLastError());
         return WW_OK;
     }

@@ -152,9 +152,12 @@ __global__ __launch_bounds__(512) void lstm_fc_kernel(const float* __restrict__ 
 using half8_t = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4_t = __attribute__((ext_vector_type(4))) uint32_t;
 
+// descale: [768] 2^-S per packed gate column (the weights' per-row scales); rowscale: LDS [16] 2^e per clip (the input row was
+// stored as x * 2^-e), or nullptr when the rows are unscaled (layer 1: |h| < 1).
 template <int K>
 __device__ __forceinline__ void lstm_layer_h(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
-                                             const u32x4_t* __restrict__ wt, float descale, const float* __restrict__ bias,
+                                             const u32x4_t* __restrict__ wt, const float* __restrict__ descale,
+                                             const float* __restrict__ rowscale, const float* __restrict__ bias,
                                              int hb, int lane, _Float16* __restrict__ out_h, _Float16* __restrict__ out_l,
                                              float* __restrict__ out_f, int out_stride) {
     constexpr int KS = K + 8, KB = K / 32, D = 2;
@@ -204,16 +207,20 @@ __device__ __forceinline__ void lstm_layer_h(const _Float16* __restrict__ xh, co
         __builtin_amdgcn_sched_barrier(0);
     }
     // D: lane&15 = hidden unit within the half, register j <-> clip 4*(lane>>4) + j
+    float rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rs[j] = rowscale ? rowscale[4 * kq + j] : 1.0f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int u = 16 * h + col;
         const float b_i = bias[hb * 96 + u], b_g = bias[hb * 96 + 32 + u], b_o = bias[hb * 96 + 64 + u];
+        const float d_i = descale[hb * 96 + u], d_g = descale[hb * 96 + 32 + u], d_o = descale[hb * 96 + 64 + u];
         const int unit = 32 * hb + u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int clip = 4 * kq + j;
-            const float c = sigmoidf_(fmaf(acc[0][h][j], descale, b_i)) * tanhf_(fmaf(acc[1][h][j], descale, b_g));
-            const float hv = sigmoidf_(fmaf(acc[2][h][j], descale, b_o)) * tanhf_(c);
+            const float c = sigmoidf_(fmaf(acc[0][h][j] * rs[j], d_i, b_i)) * tanhf_(fmaf(acc[1][h][j] * rs[j], d_g, b_g));
+            const float hv = sigmoidf_(fmaf(acc[2][h][j] * rs[j], d_o, b_o)) * tanhf_(c);
             if (out_f) {
                 out_f[clip * out_stride + unit] = hv;
             } else {
@@ -235,23 +242,44 @@ __global__ __launch_bounds__(512) void lstm_fc_h_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 xh[kClipsPerBlock * kXS], xl[kClipsPerBlock * kXS];
     __shared__ __attribute__((aligned(16))) _Float16 h0h[kClipsPerBlock * kHS16], h0l[kClipsPerBlock * kHS16];
     __shared__ __attribute__((aligned(16))) float h1[kClipsPerBlock * kHS];
+    __shared__ float rowscale[kClipsPerBlock];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int clip0 = blockIdx.x * kClipsPerBlock;
     const int xs = C + 8;
 
-    for (int i = tid; i < kClipsPerBlock * C; i += 512) {
-        const int r = i / C, k = i - r * C;
-        const float v = (clip0 + r < n) ? pooled[int64_t(clip0 + r) * C + k] : 0.f;
-        const _Float16 hi = static_cast<_Float16>(v);
-        xh[r * xs + k] = hi;
-        xl[r * xs + k] = static_cast<_Float16>(v - static_cast<float>(hi));
+    {
+        // row r = tid >> 5 (32 threads per clip).  The row is stored as x * 2^-e with e from its max |x| (max |x'| in
+        // [2^14, 2^15)): pooled features of any magnitude keep both f16 halves in range; 2^e goes back in at the gates.
+        const int r = tid >> 5, k0 = tid & 31;
+        const bool live = clip0 + r < n;
+        float v[4];
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (live && k0 + 32 * i < C) ? pooled[int64_t(clip0 + r) * C + k0 + 32 * i] : 0.f;
+            mx = fmaxf(mx, __builtin_fabsf(v[i]));
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        int e = int((__float_as_uint(mx) >> 23) & 0xffu) - 127 - 14;
+        e = e < -100 ? -100 : (e > 113 ? 113 : e);
+        const float down = __uint_as_float(uint32_t(127 - e) << 23);
+        if (k0 == 0) rowscale[r] = __uint_as_float(uint32_t(127 + e) << 23);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (k0 + 32 * i < C) {
+                const float vv = v[i] * down;
+                const _Float16 hi = static_cast<_Float16>(vv);
+                xh[r * xs + k0 + 32 * i] = hi;
+                xl[r * xs + k0 + 32 * i] = static_cast<_Float16>(vv - static_cast<float>(hi));
+            }
     }
     __syncthreads();
-    if (C == 64) lstm_layer_h<64>(xh, xl, w0, hs[0], b0, wave, lane, h0h, h0l, nullptr, kHS16);
-    else lstm_layer_h<128>(xh, xl, w0, hs[0], b0, wave, lane, h0h, h0l, nullptr, kHS16);
+    if (C == 64) lstm_layer_h<64>(xh, xl, w0, hs, rowscale, b0, wave, lane, h0h, h0l, nullptr, kHS16);
+    else lstm_layer_h<128>(xh, xl, w0, hs, rowscale, b0, wave, lane, h0h, h0l, nullptr, kHS16);
     __syncthreads();
-    lstm_layer_h<kHidden>(h0h, h0l, w1, hs[1], b1, wave, lane, nullptr, nullptr, h1, kHS);
+    lstm_layer_h<kHidden>(h0h, h0l, w1, hs + kGateCols, nullptr, b1, wave, lane, nullptr, nullptr, h1, kHS);
     __syncthreads();
     {
         const int o = tid >> 4, part = tid & 15, clip = o >> 1, cls = o & 1;

@@ -80,14 +80,16 @@ struct PackedLayout {
     int64_t fc_w;      // [2][256]
     int64_t fc_b;      // [2] (+2 pad)
     // split-precision images for the f16x3 kernels: W * 2^S = hi + lo (two f16) in MFMA operand order
-    int64_t conv2_hs;  // [4]: 2^-S (descale applied to the f32 accumulator), S, 0, 0
-    int64_t conv1_h;   // conv1 as a 32x32x16 f16 MFMA A operand: [hi,lo][64 lanes][4 dwords]; k = tap 0..8, k = 9: bias
+    int64_t conv2_hs;  // [64]: 2^-S per output channel (descale applied to the f32 accumulator)
+    int64_t conv1_h;   // conv1 as a 32x32x16 f16 MFMA A operand: [hi,lo][64 lanes][4 dwords]; k = tap 0..8, rest 0
+    int64_t conv1_hs;  // [4]: 2^-S of conv1 (one scale for the tensor), 0, 0, 0
     int64_t conv3_h;   // (n_conv 3) conv3 split-precision B operands for 16x16x32: [8 ntile][18 kstep = (cb*3+dx)*3+dy][hi,lo][64][4]
-    int64_t conv3_hs;  // [4]: 2^-S3
+    int64_t conv3_hs;  // [128]: 2^-S per output channel
     int64_t conv2_h16; // same weights for v_mfma_f32_16x16x32_f16: [4 ntile][9 kstep = dx*3+dy][hi,lo][64 lanes][4 dwords]
     int64_t l0_h;      // W_ih l0 split for v_mfma_f32_16x16x32_f16: [K/32][48 ntile][hi,lo][64 lanes][4 dwords], columns as l0_w
     int64_t l1_h;      // same for layer 1 (K = 256)
-    int64_t lstm_hs;   // [4]: 2^-S of layer 0, 2^-S of layer 1, 0, 0
+    int64_t lstm_hs;   // [2][768]: 2^-S per packed gate column, layer 0 then layer 1
+    int64_t range;     // [8]: l1 bound of conv1 (max over channels of sum |w|), max |b1|, the same for conv2, 0...
     int64_t total;
 };
 PackedLayout packed_layout(int n_conv);

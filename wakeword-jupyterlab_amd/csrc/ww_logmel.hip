@@ -15,6 +15,8 @@
 // applied to the 2560 mel powers instead of the 16000 samples (the peak falls out of the frame loads).
 //
 // Algorithmic HBM bytes per clip: 64,000 read + 10,240 written = 74,240.
+#include <mutex>
+
 #include "ww_internal.h"
 
 namespace ww {
@@ -472,9 +474,11 @@ static int launch_logmel_w(const float* pcm, int64_t n_clips, int64_t clip_strid
     const int64_t resident = int64_t(device_cu_count()) * L::kBlocksPerCu;   // what LDS and VGPRs admit per CU
     const int grid = int(n_clips < resident ? n_clips : resident);
     const size_t lds_bytes = sizeof(float) * L::kLdsFloats;
+    static std::mutex mu;
     static bool attr[64] = {};          // > 64 KiB of dynamic LDS (8-wave form) needs the opt-in once per device
     int dev = 0;
     WW_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
     if (dev >= 0 && dev < 64 && !attr[dev]) {
         WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<true, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
         WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));

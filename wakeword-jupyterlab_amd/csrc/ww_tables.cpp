@@ -165,14 +165,16 @@ PackedLayout packed_layout(int n_conv) {
     L.l1_b = take(kGateCols);
     L.fc_w = take(2 * kHidden);
     L.fc_b = take(4);
-    L.conv2_hs = take(4);
+    L.conv2_hs = take(64);
     L.conv3_h = n_conv == 3 ? take(8 * 18 * 2 * 64 * 4) : -1;
-    L.conv3_hs = n_conv == 3 ? take(4) : -1;
+    L.conv3_hs = n_conv == 3 ? take(128) : -1;
     L.conv1_h = take(2 * 64 * 4);
+    L.conv1_hs = take(4);
     L.conv2_h16 = take(4 * 9 * 2 * 64 * 4);
     L.l0_h = take(int64_t(L.c_last / 32) * 48 * 2 * 64 * 4);
     L.l1_h = take(int64_t(kHidden / 32) * 48 * 2 * 64 * 4);
-    L.lstm_hs = take(4);
+    L.lstm_hs = take(2 * kGateCols);
+    L.range = take(8);
     L.total = o;
     return L;
 }
@@ -191,18 +193,58 @@ static void pack_conv_b_operand(const float* w, int cout, int cin, float* out) {
                     }
 }
 
+// Split precision: every OUTPUT CHANNEL (row of the weight matrix) carries its own power-of-two scale, W' = W * 2^S with
+// max |W'| of the row in [2^12, 2^13), W' ~= hi + lo (two f16).  The scale of a row is a per-lane constant of the MFMA's
+// D layout (lane & 15 = output channel), so it costs nothing in the kernels and makes the split as good as fp32 for any
+// finite weights: an element keeps 22 significant bits unless it is more than 2^16 times smaller than the largest
+// weight of ITS OWN row, where its absolute error (2^-37 of that largest weight) is below what fp32 accumulation of the
+// row's dot product loses anyway.  The exponent is clamped to what 2^S and 2^-S can hold as normal floats.
+static int scale_exp(float wmax) {
+    if (!(wmax > 0.f) || !std::isfinite(wmax)) return 0;
+    int e = 0;
+    (void)std::frexp(wmax, &e);                 // wmax = f * 2^e, f in [0.5, 1)
+    int S = 13 - e;                             // wmax * 2^S in [2^12, 2^13)
+    return S > 120 ? 120 : (S < -100 ? -100 : S);
+}
+static void split_f16(double v, uint16_t& hb, uint16_t& lb) {
+    const float vf = float(v);
+    const _Float16 hi = static_cast<_Float16>(vf);
+    const _Float16 lo = static_cast<_Float16>(vf - static_cast<float>(hi));
+    std::memcpy(&hb, &hi, 2);
+    std::memcpy(&lb, &lo, 2);
+}
+// max |w| of each of `rows` rows of `len` contiguous weights -> exponents S[r]; descale[r] = 2^-S[r]
+static void row_scales(const float* w, int rows, int64_t len, std::vector<int>& S, float* descale) {
+    S.resize(rows);
+    for (int r = 0; r < rows; ++r) {
+        float m = 0.f;
+        for (int64_t i = 0; i < len; ++i) m = std::fmax(m, std::fabs(w[r * len + i]));
+        S[r] = scale_exp(m);
+        descale[r] = std::ldexp(1.0f, -S[r]);
+    }
+}
+// max over rows of sum |w| (the l1 operator bound of a conv layer: |out| <= max|in| * this + max|bias|)
+static float max_row_l1(const float* w, int rows, int64_t len) {
+    double best = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        double s = 0.0;
+        for (int64_t i = 0; i < len; ++i) s += std::fabs(double(w[r * len + i]));
+        best = std::fmax(best, s);
+    }
+    return float(best * (1.0 + 1e-6));
+}
+static float max_abs(const float* v, int n) {
+    float m = 0.f;
+    for (int i = 0; i < n; ++i) m = std::fmax(m, std::fabs(v[i]));
+    return m;
+}
+
 // conv2 weight [64][32][3][3] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16.
-// W' = W * 2^S (S chosen so that max|W'| lies in [2^12, 2^13): both halves stay normal f16), W' ~= hi + lo.
 // k-step ks = dx*3 + dy covers all 32 input channels of tap (dy, dx); lane (n = lane&15, kq = lane>>4) holds
-// B[k = 8kq + j][n] = W'[16*nt + n][8kq + j][dy][dx], j = 0..7, as 4 dwords.  Returns the descale 2^-S.
-static float pack_conv2_f16x3(const float* w, float* out_words16) {
-    float wmax = 0.f;
-    for (int i = 0; i < 64 * 32 * 9; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
-    int S = 0;
-    if (wmax > 0.f && std::isfinite(wmax)) S = 12 - int(std::floor(std::log2(wmax)));
-    if (S > 24) S = 24;
-    if (S < -8) S = -8;
-    const float scale = std::ldexp(1.0f, S);
+// B[k = 8kq + j][n] = W'[16*nt + n][8kq + j][dy][dx], j = 0..7, as 4 dwords.  descale[64] = 2^-S per output channel.
+static void pack_conv2_f16x3(const float* w, float* out_words16, float* descale) {
+    std::vector<int> S;
+    row_scales(w, 64, 32 * 9, S, descale);
     uint16_t* o16b = reinterpret_cast<uint16_t*>(out_words16);
     for (int nt = 0; nt < 4; ++nt)
         for (int dx = 0; dx < 3; ++dx)
@@ -211,31 +253,21 @@ static float pack_conv2_f16x3(const float* w, float* out_words16) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int co = 16 * nt + (lane & 15), ci = 8 * (lane >> 4) + j;
-                        const float v = w[((co * 32 + ci) * 3 + dy) * 3 + dx] * scale;
-                        const _Float16 hi = static_cast<_Float16>(v);
-                        const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
                         uint16_t hb, lb;
-                        std::memcpy(&hb, &hi, 2);
-                        std::memcpy(&lb, &lo, 2);
+                        split_f16(std::ldexp(double(w[((co * 32 + ci) * 3 + dy) * 3 + dx]), S[co]), hb, lb);
                         const int64_t base = ((int64_t(nt) * 9 + ks) * 2) * 64 * 8;
                         o16b[base + lane * 8 + j] = hb;
                         o16b[base + 64 * 8 + lane * 8 + j] = lb;
                     }
             }
-    return std::ldexp(1.0f, -S);
 }
 
 // conv3 weight [128][64][3][3] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16:
 // k-step ks = (cb*3 + dx)*3 + dy covers input channels 32*cb .. 32*cb+31 of tap (dy, dx); lane (n = lane&15, kq = lane>>4)
-// holds B[k = 8kq + j][n] = W'[16*nt + n][32*cb + 8kq + j][dy][dx].  Returns the descale 2^-S.
-static float pack_conv3_f16x3(const float* w, float* out_words) {
-    float wmax = 0.f;
-    for (int i = 0; i < 128 * 64 * 9; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
-    int S = 0;
-    if (wmax > 0.f && std::isfinite(wmax)) S = 12 - int(std::floor(std::log2(wmax)));
-    if (S > 24) S = 24;
-    if (S < -8) S = -8;
-    const float scale = std::ldexp(1.0f, S);
+// holds B[k = 8kq + j][n] = W'[16*nt + n][32*cb + 8kq + j][dy][dx].  descale[128] = 2^-S per output channel.
+static void pack_conv3_f16x3(const float* w, float* out_words, float* descale) {
+    std::vector<int> S;
+    row_scales(w, 128, 64 * 9, S, descale);
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
     for (int nt = 0; nt < 8; ++nt)
         for (int cb = 0; cb < 2; ++cb)
@@ -245,36 +277,31 @@ static float pack_conv3_f16x3(const float* w, float* out_words) {
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
                             const int co = 16 * nt + (lane & 15), ci = 32 * cb + 8 * (lane >> 4) + j;
-                            const float v = w[((co * 64 + ci) * 3 + dy) * 3 + dx] * scale;
-                            const _Float16 hi = static_cast<_Float16>(v);
-                            const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
                             uint16_t hb, lb;
-                            std::memcpy(&hb, &hi, 2);
-                            std::memcpy(&lb, &lo, 2);
+                            split_f16(std::ldexp(double(w[((co * 64 + ci) * 3 + dy) * 3 + dx]), S[co]), hb, lb);
                             const int64_t base = ((int64_t(nt) * 18 + ks) * 2) * 64 * 8;
                             o16[base + lane * 8 + j] = hb;
                             o16[base + 64 * 8 + lane * 8 + j] = lb;
                         }
                 }
-    return std::ldexp(1.0f, -S);
 }
 
-// conv1 weight [32][1][3][3] + bias as the A operand of v_mfma_f32_32x32x16_f16 (M = channel, K = 9 taps + bias tap):
-// lane (m = lane&31, h = lane>>5) holds A[m][k = 8h + j]: k < 9 -> w1[c][k], k == 9 -> b1[c] (its patch value is 1.0), else 0,
+// conv1 weight [32][1][3][3] as the A operand of v_mfma_f32_32x32x16_f16 (M = channel, K = 9 taps, 7 zero taps):
+// lane (m = lane&31, h = lane>>5) holds A[m][k = 8h + j] = w1[c][k] * 2^S[c] for k < 9, else 0,
 // where c = (m&3) + 4*(m>>3) + 16*((m>>2)&1): the MFMA's D rows are permuted so that an output lane (which holds rows
 // (j&3) + 8*(j>>2) + 4*(lane>>5), j = 0..15) ends up with the 16 CONTIGUOUS channels 16*(lane>>5) + j.
-static void pack_conv1_f16x3(const float* w, const float* b, float* out_words) {
+// One scale for the tensor (the kernel's descale is wave-uniform): descale[0] = 2^-S.  The bias is the MFMA's C operand.
+static void pack_conv1_f16x3(const float* w, float* out_words, float* descale) {
+    std::vector<int> S;
+    row_scales(w, 1, 32 * 9, S, descale);
+    S.assign(32, S[0]);
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
     for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
             const int mrow = lane & 31, k = 8 * (lane >> 5) + j;
             const int m = (mrow & 3) + 4 * (mrow >> 3) + 16 * ((mrow >> 2) & 1);
-            const float v = k < 9 ? w[m * 9 + k] : (k == 9 ? b[m] : 0.0f);
-            const _Float16 hi = static_cast<_Float16>(v);
-            const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
             uint16_t hb, lb;
-            std::memcpy(&hb, &hi, 2);
-            std::memcpy(&lb, &lo, 2);
+            split_f16(k < 9 ? std::ldexp(double(w[m * 9 + k]), S[m]) : 0.0, hb, lb);
             o16[lane * 8 + j] = hb;
             o16[64 * 8 + lane * 8 + j] = lb;
         }
@@ -300,19 +327,18 @@ static void pack_lstm(const float* w_ih, const float* b_ih, const float* b_hh, i
 
 // W_ih [4*hidden][K] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16, same column order as pack_lstm
 // (column c = (hb*3 + gate)*32 + u): k-block kb covers k = 32 kb .. 32 kb + 31, N-tile nt = c / 16; lane (n = lane&15,
-// kq = lane>>4) holds B[k = 8 kq + j][n] = W'[row(16 nt + n)][32 kb + 8 kq + j], j = 0..7.  W' = W * 2^S with max |W'| in
-// [2^12, 2^13).  Returns the descale 2^-S.
-static float pack_lstm_f16x3(const float* w_ih, int K, float* out_words) {
+// kq = lane>>4) holds B[k = 8 kq + j][n] = W'[row(16 nt + n)][32 kb + 8 kq + j], j = 0..7.  W' = W * 2^S per gate row;
+// descale[768] = 2^-S in packed column order.
+static void pack_lstm_f16x3(const float* w_ih, int K, float* out_words, float* descale) {
     const int goff[3] = {0, 2 * kHidden, 3 * kHidden};   // i, g, o
-    float wmax = 0.f;
-    for (int g = 0; g < 3; ++g)
-        for (int r = 0; r < kHidden; ++r)
-            for (int k = 0; k < K; ++k) wmax = std::fmax(wmax, std::fabs(w_ih[int64_t(goff[g] + r) * K + k]));
-    int S = 0;
-    if (wmax > 0.f && std::isfinite(wmax)) S = 12 - int(std::floor(std::log2(wmax)));
-    if (S > 24) S = 24;
-    if (S < -8) S = -8;
-    const float scale = std::ldexp(1.0f, S);
+    std::vector<int> S(kGateCols);
+    for (int c = 0; c < kGateCols; ++c) {
+        const int hb = c / 96, g = (c % 96) / 32, u = c % 32, row = goff[g] + 32 * hb + u;
+        float m = 0.f;
+        for (int k = 0; k < K; ++k) m = std::fmax(m, std::fabs(w_ih[int64_t(row) * K + k]));
+        S[c] = scale_exp(m);
+        descale[c] = std::ldexp(1.0f, -S[c]);
+    }
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
     for (int kb = 0; kb < K / 32; ++kb)
         for (int nt = 0; nt < kGateCols / 16; ++nt)
@@ -320,17 +346,12 @@ static float pack_lstm_f16x3(const float* w_ih, int K, float* out_words) {
                 for (int j = 0; j < 8; ++j) {
                     const int c = 16 * nt + (lane & 15), hb = c / 96, g = (c % 96) / 32, u = c % 32;
                     const int row = goff[g] + 32 * hb + u, k = 32 * kb + 8 * (lane >> 4) + j;
-                    const float v = w_ih[int64_t(row) * K + k] * scale;
-                    const _Float16 hi = static_cast<_Float16>(v);
-                    const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));
                     uint16_t hb16, lb16;
-                    std::memcpy(&hb16, &hi, 2);
-                    std::memcpy(&lb16, &lo, 2);
+                    split_f16(std::ldexp(double(w_ih[int64_t(row) * K + k]), S[c]), hb16, lb16);
                     const int64_t base = ((int64_t(kb) * (kGateCols / 16) + nt) * 2) * 64 * 8;   // in f16 units
                     o16[base + lane * 8 + j] = hb16;
                     o16[base + 64 * 8 + lane * 8 + j] = lb16;
                 }
-    return std::ldexp(1.0f, -S);
 }
 
 }  // namespace ww
@@ -392,11 +413,16 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     pack_lstm(sd->lstm_weight_ih[1], sd->lstm_bias_ih[1], sd->lstm_bias_hh[1], kHidden, out + L.l1_w, out + L.l1_b);
     std::memcpy(out + L.fc_w, sd->fc_weight, sizeof(float) * 2 * kHidden);
     std::memcpy(out + L.fc_b, sd->fc_bias, sizeof(float) * 2);
-    if (sd->n_conv == 3) out[L.conv3_hs] = pack_conv3_f16x3(sd->conv_weight[2], out + L.conv3_h);
-    pack_conv1_f16x3(sd->conv_weight[0], sd->conv_bias[0], out + L.conv1_h);
-    out[L.conv2_hs] = pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h16);
-    out[L.lstm_hs] = pack_lstm_f16x3(sd->lstm_weight_ih[0], L.c_last, out + L.l0_h);
-    out[L.lstm_hs + 1] = pack_lstm_f16x3(sd->lstm_weight_ih[1], kHidden, out + L.l1_h);
+    if (sd->n_conv == 3) pack_conv3_f16x3(sd->conv_weight[2], out + L.conv3_h, out + L.conv3_hs);
+    pack_conv1_f16x3(sd->conv_weight[0], out + L.conv1_h, out + L.conv1_hs);
+    pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h16, out + L.conv2_hs);
+    pack_lstm_f16x3(sd->lstm_weight_ih[0], L.c_last, out + L.l0_h, out + L.lstm_hs);
+    pack_lstm_f16x3(sd->lstm_weight_ih[1], kHidden, out + L.l1_h, out + L.lstm_hs + kGateCols);
+    // range bounds for the per-clip activation exponents of the f16x3 kernels: |conv_l out| <= max|in| * l1[l] + bmax[l]
+    out[L.range + 0] = max_row_l1(sd->conv_weight[0], 32, 9);
+    out[L.range + 1] = max_abs(sd->conv_bias[0], 32);
+    out[L.range + 2] = max_row_l1(sd->conv_weight[1], 64, 32 * 9);
+    out[L.range + 3] = max_abs(sd->conv_bias[1], 64);
     return WW_OK;
 }
 

@@ -30,6 +30,7 @@ class WakewordDataset(Dataset):
         self.augment = augment
         self.files = self.wakeword_files + self.negative_files
         self.labels = [1] * len(self.wakeword_files) + [0] * len(self.negative_files)
+        self.unreadable = 0        # items served as zeros because the file could not be decoded (non-WAV, corrupt, missing)
         if verbose:
             print(f"Dataset created with {len(self.files)} samples")
             print(f"Wakeword samples: {len(self.wakeword_files)}")
@@ -39,8 +40,14 @@ class WakewordDataset(Dataset):
         return len(self.files)
 
     def __getitem__(self, idx):
+        if torch.utils.data.get_worker_info() is not None:
+            # the reference's own call site is DataLoader(..., num_workers=2) (:461-463); a forked worker cannot
+            # initialise HIP, and a spawned one would build its own context per worker -- refuse instead of failing obscurely
+            raise RuntimeError("WakewordDataset.__getitem__ runs the log-mel kernel on the GPU and cannot be called from "
+                               "DataLoader worker processes: use DataLoader(..., num_workers=0) or dataset.batches(batch_size)")
         mel_spec = self.processor.process_audio_file(self.files[idx], augment=self.augment)
         if mel_spec is None:
+            self.unreadable += 1
             mel_spec = np.zeros((self.processor.config.N_MELS, N_FRAMES))
         return torch.FloatTensor(np.asarray(mel_spec, dtype=np.float32)).unsqueeze(0), torch.LongTensor([self.labels[idx]])
 
@@ -60,6 +67,9 @@ class WakewordDataset(Dataset):
                 pcm_dev = self.processor.augment_batch(pcm_dev)          # process_audio_file :134-135
             data = self.processor.mel_batch(pcm_dev, normalize=False)
             if not ok.all():
+                self.unreadable += int((~ok).sum())
+                print(f"WakewordDataset: {int((~ok).sum())} unreadable file(s) in this batch served as zeros "
+                      f"({self.unreadable} so far), e.g. {paths[int(np.argmin(ok))]}")
                 data[torch.from_numpy(~ok).to(dev)] = 0.0
             target = torch.tensor(self.labels[s:s + batch_size], dtype=torch.long, device=dev).unsqueeze(1)
             yield data, target

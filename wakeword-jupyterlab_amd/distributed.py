@@ -52,7 +52,8 @@ def all_gather_logits(local_logits: torch.Tensor, n_total: int | None = None, gr
     if n_total is not None:
         per = (n_total + world - 1) // world
     else:
-        t = torch.tensor([n_local], device=local_logits.device, dtype=torch.int64)
+        gloo = dist.get_backend(group) == "gloo"
+        t = torch.tensor([n_local], device="cpu" if gloo else local_logits.device, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         per = int(t.item())
     send = local_logits.contiguous()
@@ -60,7 +61,13 @@ def all_gather_logits(local_logits: torch.Tensor, n_total: int | None = None, gr
         send = torch.zeros((per,) + tuple(local_logits.shape[1:]), device=local_logits.device, dtype=local_logits.dtype)
         send[:n_local] = local_logits
     out = torch.empty((world * per,) + tuple(local_logits.shape[1:]), device=local_logits.device, dtype=local_logits.dtype)
-    dist.all_gather_into_tensor(out, send, group=group)
+    if send.device.type == "cuda" and dist.get_backend(group) == "gloo":
+        # rehearsal on a box with fewer GPUs than ranks (ranks share a GPU, gloo has no device path): stage through the host
+        parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(world)]
+        dist.all_gather(parts, send.cpu(), group=group)
+        out.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(out, send, group=group)
     if n_total is not None and n_total != world * per:
         out = out[:n_total]            # only the last ranks can be short with contiguous ceil-sharding
     return out
