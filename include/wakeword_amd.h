@@ -87,6 +87,22 @@ WW_API int ww_sync_timeouts(void);
 WW_API int ww_set_conv_math(int mode);
 WW_API int ww_get_conv_math(void);
 
+/* Arithmetic of the log-mel front end (K1), process-wide, default AUTO.  The reference's STFT is float64 (librosa forms
+ * window * frame in float64 and numpy.fft.rfft runs in double; wakeword_training_script.py:89-98), then everything is
+ * float32.  A float32 FFT leaves a rounding floor ~165 dB under a frame's energy: mel bands of noise-free signals that lie
+ * 60-80 dB under the clip's peak come out up to 3.4e-4 dB off (clips with a broadband floor above about -60 dB, like the
+ * benchmark's sine + noise clips, are unaffected: <= 1.5e-5 dB).
+ *   WW_LOGMEL_MATH_F32   float32 FFT for every clip (the throughput kernel)
+ *   WW_LOGMEL_MATH_F64   window product, FFT and real-input split in float64 for every clip (~4x the time)
+ *   WW_LOGMEL_MATH_AUTO  the float32 kernel, which marks the clips that have a live (unclamped) mel band on its rounding
+ *                        floor; a second launch redoes exactly those clips in float64.  <= 1e-4 dB against the float64
+ *                        reference for any signal; costs one near-empty launch when no clip is marked. */
+#define WW_LOGMEL_MATH_F32 0
+#define WW_LOGMEL_MATH_F64 1
+#define WW_LOGMEL_MATH_AUTO 2
+WW_API int ww_set_logmel_math(int mode);
+WW_API int ww_get_logmel_math(void);
+
 /* ---- front-end tables, host side (no GPU needed; lets CPU tests check them) ------------------ */
 /* librosa.filters.mel(sr=16000, n_fft=2048, n_mels=80, fmin=0, fmax=8000, htk=False,
  * norm='slaney') as used by wakeword_training_script.py:89-98 -> [80][1025] float32. */

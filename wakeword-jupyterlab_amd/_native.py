@@ -64,6 +64,8 @@ PROTOTYPES = {
     "ww_init": (C.c_int, []),
     "ww_set_conv_math": (C.c_int, [C.c_int]),
     "ww_get_conv_math": (C.c_int, []),
+    "ww_set_logmel_math": (C.c_int, [C.c_int]),
+    "ww_get_logmel_math": (C.c_int, []),
     "ww_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "ww_sync_timeouts": (C.c_int, []),
     "ww_mel_filterbank_host": (C.c_int, [C.c_void_p]),

@@ -72,6 +72,10 @@ static int g_conv_math = WW_CONV_MATH_F16X3;
 int conv_math_mode() { return g_conv_math; }
 void set_conv_math_mode(int mode) { g_conv_math = mode; }
 
+static int g_logmel_math = WW_LOGMEL_MATH_AUTO;
+int logmel_math_mode() { return g_logmel_math; }
+void set_logmel_math_mode(int mode) { g_logmel_math = mode; }
+
 static int64_t align256(int64_t b) { return (b + 255) & ~int64_t(255); }
 int64_t cnn_scratch_bytes(int64_t n, int n_conv);
 
@@ -189,6 +193,14 @@ int ww_set_conv_math(int mode) {
     return WW_OK;
 }
 int ww_get_conv_math(void) { return conv_math_mode(); }
+
+int ww_set_logmel_math(int mode) {
+    if (mode != WW_LOGMEL_MATH_F32 && mode != WW_LOGMEL_MATH_F64 && mode != WW_LOGMEL_MATH_AUTO)
+        return fail(WW_EINVAL, "unknown log-mel math mode %d", mode);
+    set_logmel_math_mode(mode);
+    return WW_OK;
+}
+int ww_get_logmel_math(void) { return logmel_math_mode(); }
 
 int ww_init(void) {
     if (int rc = require_gfx950()) return rc;

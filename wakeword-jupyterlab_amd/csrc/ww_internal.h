@@ -51,6 +51,14 @@ struct LogmelTables {
     // augmentation kernels (ww_augment.hip)
     float2 twr[1024];             // W_2048^k, k = 0..1023
     float kaiser_best[32772];     // resampler half-window: 64 zero crossings x 512 + 1 entries (+3 pad)
+    // float64 forms for the precise log-mel kernel (logmel64_kernel): the same entries, not rounded to float
+    double window_d[kNfft];
+    double2 tw1_d[7][128];
+    double2 tw2_d[7][16];
+    double2 twp_d[512];
+    // per mel band: the largest weight of the triangle and its reciprocal (the auto mode's rounding-floor test)
+    float band_wmax[kMels];
+    float band_bins[kMels];
 };
 
 void build_mel_filterbank(float* out /*[80][1025]*/);
@@ -100,6 +108,10 @@ PackedLayout packed_layout(int n_conv);
 int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
                   const int32_t* ring_pos /*nullable: streaming ring start per launch*/, int64_t ring_len,
                   float* logmel, hipStream_t stream);
+// log-mel arithmetic: 0 = f32 FFT, 1 = f64 FFT (what the reference's numpy.fft.rfft is), 2 = auto (f32, then the clips whose
+// quiet bands sit on the f32 FFT's rounding floor are redone in f64)
+int logmel_math_mode();
+void set_logmel_math_mode(int mode);
 int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment_plan* plans_host, float* out,
                    int64_t out_stride, void* workspace, hipStream_t stream);
 int64_t augment_workspace_bytes(int64_t n);

@@ -39,7 +39,8 @@ struct K1Layout {
     static constexpr int kThreads = WAVES * 64;
     static constexpr int kOffMel = WAVES * kSlab;
     static constexpr int kOffRed = kOffMel + kMels * kMelStride;
-    static constexpr int kOffPinfo = kOffRed + 16;          // [kPieces] ints
+    static constexpr int kOffFrm = kOffRed + 16;            // [2][WAVES][32] per-frame partial (energy, quietest live band): auto mode
+    static constexpr int kOffPinfo = kOffFrm + 2 * WAVES * 32;   // [kPieces] ints
     static constexpr int kOffFp0 = kOffPinfo + kPieces;     // [80] ints
     static constexpr int kOffFcnt = kOffFp0 + kMels;        // [80] ints
     static constexpr int kOffTw2 = kOffFcnt + kMels;        // [7][16] float2
@@ -141,6 +142,19 @@ __device__ __forceinline__ void load_frame(float4 (&sn)[8], __amdgpu_buffer_rsrc
     }
 }
 
+// NaN with a payload no arithmetic produces: "redo this clip in float64" (written by the float kernel in auto mode into
+// the first word of the clip's output, which the precise kernel then overwrites)
+constexpr uint32_t kRedoMark = 0x7fc5a11eu;
+// Auto mode's test.  The float FFT leaves rounding noise of about 2.4 eps^2 E / 1024 per bin under a frame of energy
+// E = sum_k |X_k|^2; a band's power P_b = sum_k M_bk |X_k|^2 then carries a relative error of ~2 sigma sqrt(wmax_b / P_b),
+// which reaches 1e-4 dB when P_b / wmax_b ~ 6e-8 E (measured on MI355X: scripts/diag_floor.py).  A frame with a live band
+// below kFloorRatio * E sends its clip to the float64 kernel.  E is estimated from the mel tile itself: the triangles
+// M_bk / wmax_b are a partition of unity over the bins, so sum_b P_b / wmax_b ~ E.
+#ifndef WW_FLOOR_RATIO
+#define WW_FLOOR_RATIO 1.0e-6f
+#endif
+constexpr float kFloorRatio = WW_FLOOR_RATIO;
+
 #ifdef WW_STAMPS
 __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
@@ -149,15 +163,17 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do {} while (0)
 #endif
 
+// mark != 0 (auto mode): a clip with a live mel band on the float FFT's rounding floor gets kRedoMark in the first word of its
+// output and is recomputed by logmel64_kernel<RING, true>, which runs behind this kernel on the same stream.
 template <bool RING, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void logmel_kernel(const float* __restrict__ pcm, int64_t clip_stride,
                                                              int clip_len, int n_clips, int normalize,
                                                              const int32_t* __restrict__ ring_pos_p, int ring_len,
                                                              const LogmelTables* __restrict__ tb,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int mark) {
     using L = K1Layout<WAVES>;
     constexpr int kWavesPerBlock = WAVES, kThreads = L::kThreads;
-    constexpr int kOffMel = L::kOffMel, kOffRed = L::kOffRed, kOffPinfo = L::kOffPinfo, kOffFp0 = L::kOffFp0,
+    constexpr int kOffMel = L::kOffMel, kOffRed = L::kOffRed, kOffFrm = L::kOffFrm, kOffPinfo = L::kOffPinfo, kOffFp0 = L::kOffFp0,
                   kOffFcnt = L::kOffFcnt, kOffTw2 = L::kOffTw2, kOffTwp = L::kOffTwp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mel = lds + kOffMel;                                 // [80][33]
@@ -443,14 +459,40 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
         ref = ref < amin ? amin : ref;
         const float ref_db = db10(ref);
         float* __restrict__ o = out + int64_t(clip) * (kMels * kFrames);
+        // auto mode: per frame (= tid & 31 for every idx of this thread) the energy estimate sum_b P_b / wmax_b and the
+        // quietest live band min_b P_b / wmax_b; live = not clamped by top_db (with a 1 % margin) nor by amin
+        float e_part = 0.f, q_part = 3.0e38f;
+        const float live_thr = fmaxf(mmax * 0.99e-8f, amin / g2);
         for (int idx = tid; idx < kMels * kFrames; idx += kThreads) {
-            float v = mel[(idx >> 5) * kMelStride + (idx & 31)] * g2;
+            const float p = mel[(idx >> 5) * kMelStride + (idx & 31)];
+            float v = p * g2;
             v = v < amin ? amin : v;
             float db = db10(v) - ref_db;
             db = db < -80.0f ? -80.0f : db;
             o[idx] = db;
+            if (mark) {
+                const float u = p * tb->band_bins[idx >> 5];            // band_bins = 1 / wmax here (see ww_tables.cpp)
+                e_part += u;
+                q_part = p > live_thr ? fminf(q_part, u) : q_part;
+            }
         }
-        __syncthreads();   // mel / red are rewritten by the next clip
+        if (mark) {                                                     // uniform
+            float* frm = lds + kOffFrm;
+            e_part += __shfl_xor(e_part, 32);
+            q_part = fminf(q_part, __shfl_xor(q_part, 32));
+            if (lane < 32) { frm[wave * 32 + lane] = e_part; frm[(kWavesPerBlock + wave) * 32 + lane] = q_part; }
+            __syncthreads();
+            bool redo = false;
+            if (tid < 32) {
+                float e = 0.f, q = 3.0e38f;
+#pragma unroll
+                for (int w = 0; w < kWavesPerBlock; ++w) { e += frm[w * 32 + tid]; q = fminf(q, frm[(kWavesPerBlock + w) * 32 + tid]); }
+                redo = q < kFloorRatio * e;                             // false for NaN / empty frames
+            }
+            if (wave == 0 && __builtin_amdgcn_ballot_w64(redo) != 0ull && lane == 0)
+                reinterpret_cast<uint32_t*>(o)[0] = kRedoMark;          // after this thread's own store of o[0]
+        }
+        __syncthreads();   // mel / red / frm are rewritten by the next clip
         STAMP(7);
     }
 #ifdef WW_STAMPS
@@ -467,30 +509,340 @@ extern "C" __attribute__((visibility("default"))) int ww_debug_stamps(unsigned l
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// Precise form: the SAME transform with the window product, the 1024-point FFT and the real-input split in float64 --
+// what the reference computes (librosa forms window * frame in float64 and calls numpy.fft.rfft, which runs in double,
+// then rounds the spectrum to complex64: /root/reference/wakeword_training_script.py:89-98).  A float32 FFT leaves a
+// rounding floor ~165 dB under the frame's energy; mel bands of noise-free signals (pure tones, clean speech with digital
+// silence) that lie 60-80 dB under the clip's peak sit on it and come out up to 3.4e-4 dB off.  This kernel is selected
+// by ww_set_logmel_math(WW_LOGMEL_MATH_F64), or per clip by the auto mode (below).
+// Same radix 8 x 8 x 16 structure and the same exchange index maps as the float kernel, with a 16-byte complex as the
+// unit (two ds_read/write_b128 per pair); power spectrum, sparse mel and the dB epilogue are the float kernel's.
+// 4 waves, one 93 KB workgroup per CU.  ONLY_FLAGGED: redo only the clips the float kernel marked (auto mode).
+// ------------------------------------------------------------------------------------------------
+struct cd { double x, y; };
+struct alignas(16) cd2 { cd a, b; };      // two complex doubles = one exchange unit
+__device__ __forceinline__ cd operator+(cd a, cd b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cmul(cd a, cd b) { return {fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x)}; }
+__device__ __forceinline__ cd mul_neg_i(cd a) { return {a.y, -a.x}; }
+__device__ __forceinline__ void dft4(cd& a0, cd& a1, cd& a2, cd& a3) {
+    const cd t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_neg_i(a1 - a3);
+    a0 = t0 + t2; a2 = t0 - t2; a1 = t1 + t3; a3 = t1 - t3;
+}
+__device__ __forceinline__ void dft8(cd (&v)[8]) {
+    constexpr double c = 0.70710678118654752440;
+    cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cd o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+    o1 = {c * (o1.x + o1.y), c * (o1.y - o1.x)};
+    o2 = mul_neg_i(o2);
+    o3 = {c * (o3.y - o3.x), -c * (o3.x + o3.y)};
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+__device__ __forceinline__ void dft16(cd (&v)[16]) {
+    cd e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    dft8(e);
+    dft8(o);
+    constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, c2 = 0.70710678118654752440;
+    const cd w[8] = {{1., 0.}, {c1, -s1}, {c2, -c2}, {s1, -c1}, {0., -1.}, {-s1, -c1}, {-c2, -c2}, {-c1, -s1}};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const cd t = (k == 0) ? o[0] : (k == 4 ? mul_neg_i(o[4]) : cmul(o[k], w[k]));
+        v[k] = e[k] + t;
+        v[k + 8] = e[k] - t;
+    }
+}
+
+constexpr int kSlab64 = 2 * 2048 + 8;                       // floats per wave: 1024 complex doubles (+ pad)
+constexpr int k64OffMel = 4 * kSlab64;
+constexpr int k64OffRed = k64OffMel + kMels * kMelStride;
+constexpr int k64OffPinfo = k64OffRed + 16;
+constexpr int k64OffFp0 = k64OffPinfo + kPieces;
+constexpr int k64OffFcnt = k64OffFp0 + kMels;
+constexpr int k64OffTw2 = (k64OffFcnt + kMels + 3) & ~3;     // [7][16] complex doubles
+constexpr int k64OffTwp = k64OffTw2 + 7 * 16 * 4;           // [512] complex doubles
+constexpr int k64LdsFloats = k64OffTwp + 512 * 4;
+static_assert(k64OffMel % 4 == 0 && k64OffTw2 % 4 == 0, "16-byte alignment of the double tables");
+
+template <bool RING, bool ONLY_FLAGGED>
+__global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restrict__ pcm, int64_t clip_stride, int clip_len, int n_clips,
+                                                          int normalize, const int32_t* __restrict__ ring_pos_p, int ring_len,
+                                                          const LogmelTables* __restrict__ tb, float* __restrict__ out) {
+    constexpr int kWavesPerBlock = 4, kThreads = 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* mel = lds + k64OffMel;
+    float* red = lds + k64OffRed;
+    const int* pinfo = reinterpret_cast<const int*>(lds + k64OffPinfo);
+    const int* fp0 = reinterpret_cast<const int*>(lds + k64OffFp0);
+    const int* fcnt = reinterpret_cast<const int*>(lds + k64OffFcnt);
+    const cd2* tw2_u = reinterpret_cast<const cd2*>(lds + k64OffTw2);      // [7][8] units = two twiddles each
+    const cd* twp_c = reinterpret_cast<const cd*>(lds + k64OffTwp);
+    const float4* pw4 = reinterpret_cast<const float4*>(&tb->piece_w[0][0][0]);
+    const cd2* tw1_u = reinterpret_cast<const cd2*>(&tb->tw1_d[0][0]);     // [7][64] units
+    const double* win = &tb->window_d[0];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* slabf = lds + wave * kSlab64;                        // power spectrum / piece sums (floats) reuse the slab
+    cd2* slabu = reinterpret_cast<cd2*>(slabf);                 // exchange units (the float kernel's float4 indices)
+    cd* slabc = reinterpret_cast<cd*>(slabf);                   // single complex values (the float kernel's float2 indices)
+    float* partial = slabf + kPartialInSlab;
+
+    for (int i = tid; i < kPieces; i += kThreads) reinterpret_cast<int*>(lds)[k64OffPinfo + i] = tb->piece_info[i];
+    if (tid < kMels) {
+        reinterpret_cast<int*>(lds)[k64OffFp0 + tid] = tb->filt_p0[tid];
+        reinterpret_cast<int*>(lds)[k64OffFcnt + tid] = tb->filt_cnt[tid];
+    }
+    for (int i = tid; i < 7 * 16 * 2; i += kThreads) reinterpret_cast<double*>(lds + k64OffTw2)[i] = (&tb->tw2_d[0][0].x)[i];
+    for (int i = tid; i < 512 * 2; i += kThreads) reinterpret_cast<double*>(lds + k64OffTwp)[i] = (&tb->twp_d[0].x)[i];
+    const int ring_pos = RING ? *ring_pos_p : 0;
+    __syncthreads();
+    const int my_p0a = fp0[lane], my_cnta = fcnt[lane];
+    const int my_p0b = lane + 64 < kMels ? fp0[lane + 64] : 0, my_cntb = lane + 64 < kMels ? fcnt[lane + 64] : 0;
+    const unsigned clip_bytes = unsigned(clip_len) * 4u;
+
+#pragma unroll 1
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+        float* __restrict__ o = out + int64_t(clip) * (kMels * kFrames);
+        if constexpr (ONLY_FLAGGED) {
+            if (__builtin_amdgcn_readfirstlane(__float_as_uint(__builtin_nontemporal_load(o))) != kRedoMark) continue;   // uniform
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm + int64_t(clip) * clip_stride), 0,
+                                                                             clip_bytes, 0x00020000);
+        float peak = 0.f;
+#pragma unroll 1
+        for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
+            const int frame = round * kWavesPerBlock + wave;
+            const int k1r = lane >> 3, jr = lane & 7;
+            float4 sn[8];
+            load_frame<RING>(sn, rs, frame * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
+            cd za[8], zb[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const float4 s = sn[n1];
+                const double* w = win + 4 * (64 * n1 + lane);
+                if (n1 == 4 || n1 == 5) peak = absmax3(s.z, s.w, absmax3(s.x, s.y, peak));
+                za[n1] = {double(s.x) * w[0], double(s.y) * w[1]};
+                zb[n1] = {double(s.z) * w[2], double(s.w) * w[3]};
+            }
+            // ---- pass 1 ----
+            dft8(za);
+            dft8(zb);
+            slabu[lane] = {za[0], zb[0]};
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) {
+                const cd2 t = tw1_u[(k1 - 1) * 64 + lane];
+                slabu[k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)))] = {cmul(za[k1], t.a), cmul(zb[k1], t.b)};
+            }
+            lds_order();
+            // ---- pass 2 ----
+            {
+                const int s8 = 8 * ((k1r >> 1) & 1);
+                const cd2* x1e = slabu + k1r * 64 + jr + s8;
+                const cd2* x1o = slabu + k1r * 64 + jr - s8;
+#pragma unroll
+                for (int n2 = 0; n2 < 8; ++n2) {
+                    const cd2 v = (n2 & 1) ? x1o[n2 * 8] : x1e[n2 * 8];
+                    za[n2] = v.a;
+                    zb[n2] = v.b;
+                }
+                lds_order();
+                dft8(za);
+                dft8(zb);
+                cd2* x2w[4];
+#pragma unroll
+                for (int hk = 0; hk < 4; ++hk) x2w[hk] = slabu + 64 * k1r + (jr ^ (4 * (k1r & 1) + hk));
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    cd a = za[k2], b = zb[k2];
+                    if (k2 > 0) {
+                        const cd2 t = tw2_u[(k2 - 1) * 8 + jr];
+                        a = cmul(a, t.a);
+                        b = cmul(b, t.b);
+                    }
+                    x2w[k2 >> 1][8 * k2] = {a, b};
+                }
+            }
+            lds_order();
+            // ---- pass 3 ----
+            {
+                cd u[16];
+                const int sw2 = (lane >> 1) & 7;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const cd2 v = slabu[lane * 8 + (m ^ sw2)];
+                    u[2 * m] = v.a;
+                    u[2 * m + 1] = v.b;
+                }
+                lds_order();
+                dft16(u);
+                const int lp = (lane >> 3) + 8 * (lane & 7);
+                cd* zw = slabc + (lp ^ (((lp >> 4) & 3) << 1));
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) zw[64 * kk] = u[kk];
+            }
+            lds_order();
+            // ---- real-input split (float64), rounded to complex64 like the reference's spectrum, power in float32 ----
+            {
+                cd a[8], b[8];
+                const int lowb = (64 - lane) & 63;
+                const cd* za_p = slabc + (lane ^ (((lane >> 4) & 3) << 1));
+                const cd* zb_p = slabc + (lowb ^ (((lowb >> 4) & 3) << 1)) + (lane == 0 ? 64 : 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a[j] = za_p[64 * j];
+                    b[j] = zb_p[64 * (15 - j)];
+                }
+                if (lane == 0) { a[0] = slabc[512]; b[0] = a[0]; }
+                lds_order();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = (j == 0 && lane == 0) ? 512 : lane + 64 * j;
+                    const cd tw = twp_c[lane + 64 * j];
+                    const cd e = {0.5 * (a[j].x + b[j].x), 0.5 * (a[j].y - b[j].y)};
+                    const cd od = {0.5 * (a[j].y + b[j].y), 0.5 * (b[j].x - a[j].x)};
+                    const cd t = cmul(od, tw);
+                    const float px = float(e.x + t.x), py = float(e.y + t.y), mx = float(e.x - t.x), my = float(e.y - t.y);
+                    slabf[k] = fmaf(px, px, py * py);
+                    slabf[1024 - k] = fmaf(mx, mx, my * my);
+                }
+                if (lane == 0) slabf[0] = 0.f;
+            }
+            lds_order();
+            // ---- sparse mel (as the float kernel) ----
+            {
+                int info[kPieceRounds];
+                float4 s0[kPieceRounds], s1[kPieceRounds], pw0[kPieceRounds], pw1[kPieceRounds];
+#pragma unroll
+                for (int c = 0; c < kPieceRounds; ++c) {
+                    info[c] = pinfo[c * kPieceSlots + lane];
+                    pw0[c] = pw4[c * kPieceSlots + lane];
+                    pw1[c] = pw4[kPieces + c * kPieceSlots + lane];
+                }
+#pragma unroll
+                for (int c = 0; c < kPieceRounds; ++c) {
+                    const float4* s4 = reinterpret_cast<const float4*>(slabf + (info[c] & 0xffff));
+                    s0[c] = s4[0];
+                    s1[c] = s4[1];
+                }
+#pragma unroll
+                for (int c = 0; c < kPieceRounds; ++c) {
+                    const float4 w0 = pw0[c], w1 = pw1[c];
+                    float acc = w0.x * s0[c].x;
+                    acc = fmaf(w0.y, s0[c].y, acc);
+                    acc = fmaf(w0.z, s0[c].z, acc);
+                    acc = fmaf(w0.w, s0[c].w, acc);
+                    acc = fmaf(w1.x, s1[c].x, acc);
+                    acc = fmaf(w1.y, s1[c].y, acc);
+                    acc = fmaf(w1.z, s1[c].z, acc);
+                    acc = fmaf(w1.w, s1[c].w, acc);
+                    partial[info[c] >> 16] = acc;
+                }
+                lds_order();
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int f = lane + 64 * pass;
+                    const int p0 = pass ? my_p0b : my_p0a, cnt = pass ? my_cntb : my_cnta;
+                    if (f < kMels) {
+                        float acc = 0.f;
+                        for (int q = 0; q < cnt; ++q) acc += partial[p0 + q];
+                        mel[f * kMelStride + frame] = acc;
+                    }
+                }
+            }
+            lds_order();
+        }
+        __syncthreads();
+        float mmax = 0.f;
+        for (int idx = tid; idx < kMels * kFrames; idx += kThreads) mmax = fmaxf(mmax, mel[(idx >> 5) * kMelStride + (idx & 31)]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mmax = fmaxf(mmax, __shfl_xor(mmax, off));
+            peak = fmaxf(peak, __shfl_xor(peak, off));
+        }
+        if (lane == 0) { red[wave] = mmax; red[kWavesPerBlock + wave] = peak; }
+        __syncthreads();
+        mmax = red[0];
+        peak = red[kWavesPerBlock];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) { mmax = fmaxf(mmax, red[w]); peak = fmaxf(peak, red[kWavesPerBlock + w]); }
+        const float amin = 1e-10f;
+        float g2 = 1.f;
+        if (normalize) { const float g = 1.0f / peak; g2 = g * g; }
+        float ref = mmax * g2;
+        ref = ref < amin ? amin : ref;
+        const float ref_db = db10(ref);
+        for (int idx = tid; idx < kMels * kFrames; idx += kThreads) {
+            float v = mel[(idx >> 5) * kMelStride + (idx & 31)] * g2;
+            v = v < amin ? amin : v;
+            float db = db10(v) - ref_db;
+            db = db < -80.0f ? -80.0f : db;
+            o[idx] = db;
+        }
+        __syncthreads();
+    }
+}
+
 template <int WAVES>
 static int launch_logmel_w(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
-                           const int32_t* ring_pos, int64_t ring_len, float* logmel, const LogmelTables* tb, hipStream_t stream) {
+                           const int32_t* ring_pos, int64_t ring_len, float* logmel, const LogmelTables* tb, int mark, hipStream_t stream) {
     using L = K1Layout<WAVES>;
     const int64_t resident = int64_t(device_cu_count()) * L::kBlocksPerCu;   // what LDS and VGPRs admit per CU
     const int grid = int(n_clips < resident ? n_clips : resident);
     const size_t lds_bytes = sizeof(float) * L::kLdsFloats;
-    static std::mutex mu;
-    static bool attr[64] = {};          // > 64 KiB of dynamic LDS (8-wave form) needs the opt-in once per device
-    int dev = 0;
-    WW_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    if (dev >= 0 && dev < 64 && !attr[dev]) {
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<true, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-        attr[dev] = true;
-    }
     if (ring_pos)
         hipLaunchKernelGGL((logmel_kernel<true, WAVES>), dim3(grid), dim3(L::kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
-                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
+                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel, mark);
     else
         hipLaunchKernelGGL((logmel_kernel<false, WAVES>), dim3(grid), dim3(L::kThreads), lds_bytes, stream, pcm, clip_stride, int(clip_len),
+                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel, mark);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+template <bool ONLY_FLAGGED>
+static int launch_logmel64(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
+                           const int32_t* ring_pos, int64_t ring_len, float* logmel, const LogmelTables* tb, hipStream_t stream) {
+    const int cus = device_cu_count();
+    const int grid = int(n_clips < cus ? n_clips : cus);
+    const size_t lds_bytes = sizeof(float) * k64LdsFloats;
+    if (ring_pos)
+        hipLaunchKernelGGL((logmel64_kernel<true, ONLY_FLAGGED>), dim3(grid), dim3(256), lds_bytes, stream, pcm, clip_stride, int(clip_len),
+                           int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
+    else
+        hipLaunchKernelGGL((logmel64_kernel<false, ONLY_FLAGGED>), dim3(grid), dim3(256), lds_bytes, stream, pcm, clip_stride, int(clip_len),
                            int(n_clips), normalize, ring_pos, int(ring_len), tb, logmel);
     WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// > 64 KiB of dynamic LDS needs an opt-in per kernel, once per device
+static int logmel_opt_in_lds() {
+    static std::mutex mu;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    WW_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
+    if (done[dev]) return WW_OK;
+    const int b4 = int(sizeof(float) * K1Layout<4>::kLdsFloats), b8 = int(sizeof(float) * K1Layout<8>::kLdsFloats);
+    const int b64 = int(sizeof(float) * k64LdsFloats);
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, b4));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, b4));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, b8));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, b8));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, b64));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, b64));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, b64));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel64_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, b64));
+    done[dev] = true;
     return WW_OK;
 }
 
@@ -499,10 +851,19 @@ int launch_logmel(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_
     if (n_clips == 0) return WW_OK;
     const LogmelTables* tb = device_tables();
     if (!tb) return WW_EHIP;
+    if (int rc = logmel_opt_in_lds()) return rc;
+    const int mode = logmel_math_mode();
+    if (mode == WW_LOGMEL_MATH_F64)
+        return launch_logmel64<false>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, stream);
+    const int mark = mode == WW_LOGMEL_MATH_AUTO;
     // at most one clip per CU (streaming, small batches): the 8-wave latency form; otherwise the 4-wave throughput form
+    int rc;
     if (n_clips <= device_cu_count())
-        return launch_logmel_w<8>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, stream);
-    return launch_logmel_w<4>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, stream);
+        rc = launch_logmel_w<8>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, mark, stream);
+    else
+        rc = launch_logmel_w<4>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, mark, stream);
+    if (rc != WW_OK || !mark) return rc;
+    return launch_logmel64<true>(pcm, n_clips, clip_stride, clip_len, normalize, ring_pos, ring_len, logmel, tb, stream);
 }
 
 }  // namespace ww

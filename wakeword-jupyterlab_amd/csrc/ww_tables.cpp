@@ -87,27 +87,40 @@ void build_kaiser_best(float* out) {
     }
 }
 
-static float2 twiddle(int N, long e) {   // W_N^e = exp(-2*pi*i*e/N), argument reduced exactly
+static double2 twiddle_d(int N, long e) {   // W_N^e = exp(-2*pi*i*e/N), argument reduced exactly
     e %= N;
     const double a = -2.0 * M_PI * double(e) / double(N);
-    return make_float2(float(std::cos(a)), float(std::sin(a)));
+    double2 r;
+    r.x = std::cos(a);
+    r.y = std::sin(a);
+    return r;
+}
+static float2 twiddle(int N, long e) {
+    const double2 t = twiddle_d(N, e);
+    return make_float2(float(t.x), float(t.y));
 }
 
 int build_logmel_tables(LogmelTables* t) {
     std::memset(t, 0, sizeof(*t));
     std::vector<double> w(kNfft);
     build_hann(w.data());
-    for (int n = 0; n < kNfft; ++n) t->window[n] = float(w[n]);
+    for (int n = 0; n < kNfft; ++n) { t->window[n] = float(w[n]); t->window_d[n] = w[n]; }
     for (int k1 = 1; k1 < 8; ++k1)
-        for (int n = 0; n < 128; ++n) t->tw1[k1 - 1][n] = twiddle(1024, long(n) * k1);
+        for (int n = 0; n < 128; ++n) { t->tw1[k1 - 1][n] = twiddle(1024, long(n) * k1); t->tw1_d[k1 - 1][n] = twiddle_d(1024, long(n) * k1); }
     for (int k2 = 1; k2 < 8; ++k2)
-        for (int n = 0; n < 16; ++n) t->tw2[k2 - 1][n] = twiddle(128, long(n) * k2);
-    for (int k = 0; k < 512; ++k) t->twp[k] = twiddle(2048, k == 0 ? 512 : k);
+        for (int n = 0; n < 16; ++n) { t->tw2[k2 - 1][n] = twiddle(128, long(n) * k2); t->tw2_d[k2 - 1][n] = twiddle_d(128, long(n) * k2); }
+    for (int k = 0; k < 512; ++k) { t->twp[k] = twiddle(2048, k == 0 ? 512 : k); t->twp_d[k] = twiddle_d(2048, k == 0 ? 512 : k); }
     for (int k = 0; k < 1024; ++k) t->twr[k] = twiddle(2048, k);
     build_kaiser_best(t->kaiser_best);
 
     std::vector<float> M(size_t(kMels) * kBins);
     build_mel_filterbank(M.data());
+    for (int f = 0; f < kMels; ++f) {
+        float wmax = 0.f;
+        for (int k = 0; k < kBins; ++k) wmax = std::fmax(wmax, M[f * kBins + k]);
+        t->band_wmax[f] = wmax;
+        t->band_bins[f] = 1.0f / wmax;              // the kernel's multiplier: P_b / wmax_b
+    }
     struct Piece { int m, f, pos; };
     std::vector<Piece> pieces;
     int pos = 0;

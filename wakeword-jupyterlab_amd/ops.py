@@ -248,6 +248,22 @@ def get_conv_math() -> str:
     return {v: k for k, v in CONV_MATH.items()}[nat.lib.ww_get_conv_math()]
 
 
+LOGMEL_MATH = {"f32": 0, "f64": 1, "auto": 2}
+
+
+def set_logmel_math(mode: str) -> None:
+    """Arithmetic of the log-mel front end, process-wide: 'f32' (float32 FFT), 'f64' (float64 window product / FFT / split, what
+    the reference's numpy.fft.rfft computes) or 'auto' (default: float32, and the clips with a live mel band on the float32
+    FFT's rounding floor are redone in float64)."""
+    if mode not in LOGMEL_MATH:
+        raise ValueError(f"log-mel math {mode!r}: expected one of {sorted(LOGMEL_MATH)}")
+    nat.check(nat.lib.ww_set_logmel_math(LOGMEL_MATH[mode]))
+
+
+def get_logmel_math() -> str:
+    return {v: k for k, v in LOGMEL_MATH.items()}[nat.lib.ww_get_logmel_math()]
+
+
 def init() -> None:
     """Upload the front-end tables for the current device (needed before hipGraph capture)."""
     nat.check(nat.lib.ww_init())
@@ -257,6 +273,8 @@ import os as _os  # noqa: E402
 
 if _os.environ.get("WW_CONV_MATH"):
     set_conv_math(_os.environ["WW_CONV_MATH"])
+if _os.environ.get("WW_LOGMEL_MATH"):
+    set_logmel_math(_os.environ["WW_LOGMEL_MATH"])
 
 
 # ---- KA: augmentation ------------------------------------------------------------------
