@@ -147,11 +147,11 @@ __device__ __forceinline__ void load_frame(float4 (&sn)[8], __amdgpu_buffer_rsrc
 constexpr uint32_t kRedoMark = 0x7fc5a11eu;
 // Auto mode's test.  The float FFT leaves rounding noise of about 2.4 eps^2 E / 1024 per bin under a frame of energy
 // E = sum_k |X_k|^2; a band's power P_b = sum_k M_bk |X_k|^2 then carries a relative error of ~2 sigma sqrt(wmax_b / P_b),
-// which reaches 1e-4 dB when P_b / wmax_b ~ 6e-8 E (measured on MI355X: scripts/diag_floor.py).  A frame with a live band
+// which exceeds 1e-4 dB below P_b / wmax_b ~ 4e-6 E (measured on MI355X: scripts/diag_floor.py).  A frame with a live band
 // below kFloorRatio * E sends its clip to the float64 kernel.  E is estimated from the mel tile itself: the triangles
 // M_bk / wmax_b are a partition of unity over the bins, so sum_b P_b / wmax_b ~ E.
 #ifndef WW_FLOOR_RATIO
-#define WW_FLOOR_RATIO 1.0e-6f
+#define WW_FLOOR_RATIO 1.0e-5f
 #endif
 constexpr float kFloorRatio = WW_FLOOR_RATIO;
 
@@ -616,7 +616,26 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
         }
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm + int64_t(clip) * clip_stride), 0,
                                                                              clip_bytes, 0x00020000);
+        // The reference normalises BEFORE the transform, in float32 (audio / np.max(np.abs(audio)), :73-76): every sample is
+        // rounded once more, and that rounding is white noise ~177 dB under a tone's peak bin -- visible (2e-4 dB) in bands 85 dB
+        // under the frame's energy.  So this kernel does the same: peak first (loads n1 = 4, 5 of the 32 frames tile the clip once),
+        // then x / peak as a correctly rounded float division.
         float peak = 0.f;
+        if (normalize) {
+#pragma unroll 1
+            for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
+                float4 sn[8];
+                load_frame<RING>(sn, rs, (round * kWavesPerBlock + wave) * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
+                peak = absmax3(sn[4].z, sn[4].w, absmax3(sn[4].x, sn[4].y, peak));
+                peak = absmax3(sn[5].z, sn[5].w, absmax3(sn[5].x, sn[5].y, peak));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) peak = fmaxf(peak, __shfl_xor(peak, off));
+            if (lane == 0) red[wave] = peak;
+            __syncthreads();
+            peak = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
             const int frame = round * kWavesPerBlock + wave;
@@ -626,9 +645,9 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
             cd za[8], zb[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
-                const float4 s = sn[n1];
+                float4 s = sn[n1];
+                if (normalize) { s.x = __fdiv_rn(s.x, peak); s.y = __fdiv_rn(s.y, peak); s.z = __fdiv_rn(s.z, peak); s.w = __fdiv_rn(s.w, peak); }
                 const double* w = win + 4 * (64 * n1 + lane);
-                if (n1 == 4 || n1 == 5) peak = absmax3(s.z, s.w, absmax3(s.x, s.y, peak));
                 za[n1] = {double(s.x) * w[0], double(s.y) * w[1]};
                 zb[n1] = {double(s.z) * w[2], double(s.w) * w[3]};
             }
@@ -760,27 +779,28 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
             lds_order();
         }
         __syncthreads();
+        // a NaN anywhere (silent clip, 0/0) must reach every output like in the reference: fmaxf would drop it
         float mmax = 0.f;
-        for (int idx = tid; idx < kMels * kFrames; idx += kThreads) mmax = fmaxf(mmax, mel[(idx >> 5) * kMelStride + (idx & 31)]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mmax = fmaxf(mmax, __shfl_xor(mmax, off));
-            peak = fmaxf(peak, __shfl_xor(peak, off));
+        bool any_nan = false;
+        for (int idx = tid; idx < kMels * kFrames; idx += kThreads) {
+            const float p = mel[(idx >> 5) * kMelStride + (idx & 31)];
+            any_nan |= p != p;
+            mmax = fmaxf(mmax, p);
         }
-        if (lane == 0) { red[wave] = mmax; red[kWavesPerBlock + wave] = peak; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, off));
+        any_nan = __builtin_amdgcn_ballot_w64(any_nan) != 0ull;
+        if (lane == 0) red[wave] = any_nan ? __uint_as_float(0x7fc00000u) : mmax;
         __syncthreads();
         mmax = red[0];
-        peak = red[kWavesPerBlock];
 #pragma unroll
-        for (int w = 1; w < kWavesPerBlock; ++w) { mmax = fmaxf(mmax, red[w]); peak = fmaxf(peak, red[kWavesPerBlock + w]); }
+        for (int w = 1; w < kWavesPerBlock; ++w) mmax = (red[w] != red[w] || mmax != mmax) ? __uint_as_float(0x7fc00000u) : fmaxf(mmax, red[w]);
         const float amin = 1e-10f;
-        float g2 = 1.f;
-        if (normalize) { const float g = 1.0f / peak; g2 = g * g; }
-        float ref = mmax * g2;
+        float ref = mmax;
         ref = ref < amin ? amin : ref;
         const float ref_db = db10(ref);
         for (int idx = tid; idx < kMels * kFrames; idx += kThreads) {
-            float v = mel[(idx >> 5) * kMelStride + (idx & 31)] * g2;
+            float v = mel[(idx >> 5) * kMelStride + (idx & 31)];
             v = v < amin ? amin : v;
             float db = db10(v) - ref_db;
             db = db < -80.0f ? -80.0f : db;
