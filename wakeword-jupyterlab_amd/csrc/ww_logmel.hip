@@ -590,6 +590,14 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (ONLY_FLAGGED) {
+        // auto mode, usually nothing to do: look at the marks of all this workgroup's clips at once and leave before the
+        // tables are staged (the launch then costs a few microseconds)
+        int any = 0;
+        for (int c = int(blockIdx.x) + tid * int(gridDim.x); c < n_clips; c += kThreads * int(gridDim.x))
+            any |= __float_as_uint(__builtin_nontemporal_load(out + int64_t(c) * (kMels * kFrames))) == kRedoMark;
+        if (!__syncthreads_or(any)) return;
+    }
     float* slabf = lds + wave * kSlab64;                        // power spectrum / piece sums (floats) reuse the slab
     cd2* slabu = reinterpret_cast<cd2*>(slabf);                 // exchange units (the float kernel's float4 indices)
     cd* slabc = reinterpret_cast<cd*>(slabf);                   // single complex values (the float kernel's float2 indices)
