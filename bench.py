@@ -17,6 +17,8 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   stages        the same for K1 (HBM roofline, 74,240 algorithmic bytes per clip) and K3 (gate GEMMs)
   cpu_baseline  the CPU oracle (numpy log-mel per clip + torch CPU Conv2d/LSTM/Linear) timed on this
                 host on a bounded sample of the same clips (rank 0, N = 1 only)
+  sustained     >= 2 s of back-to-back steps after the timed region (the driver's K steps last ~20 ms: too short to show the
+                clock the chip holds under load): clips/s and per-kernel means over that leg
   parity        max |err| of the measured path against that oracle on the sample
   augmentation  augment_audio on the GPU: clips/s for plans drawn like the reference, error vs the oracle
   streaming     BASELINE configs[4] (256 microphones, 10 ms hop, hipGraph replay per hop): p50/p99 hop latency, hops/s
@@ -65,6 +67,22 @@ def pmc_traffic(kernel, batch, arch):
     return None
 
 
+def pmc_busy(kernel, batch, arch):
+    """Matrix-pipe busy fraction of a kernel from the newest committed PMC pass (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x
+    kernel cycles), profiles/r*_pmc_traffic.json) -- what north_star calls MFMA utilisation of the gate GEMM."""
+    import glob
+    if batch != 4096 or arch != "simple":
+        return {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            for name, d in json.load(open(path))["sq_counters_mean"].items():
+                if kernel in name and "mfma_pipe_busy_frac" in d:
+                    return {"mfma_pipe_busy_frac_pmc": d["mfma_pipe_busy_frac"], "pmc_source": os.path.basename(path)}
+        except Exception:
+            continue
+    return {}
+
+
 def cpu_baseline(clips, sd, budget_s=20.0):
     """The reference path restated on the CPU (oracle/): per-clip numpy log-mel, then torch CPU layers."""
     from oracle import mel_oracle, model_oracle
@@ -102,6 +120,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true", help="skip the streaming (256 mics, 10 ms hop) latency leg")
     ap.add_argument("--conv-math", default=None, choices=["f32", "f16x3"], help="conv2 arithmetic (default: library default)")
+    ap.add_argument("--logmel-math", default=None, choices=["f32", "f64", "auto"], help="log-mel arithmetic (default: library default, auto)")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="length of the sustained leg after the timed region (0 = skip)")
     args = ap.parse_args()
 
     import wakeword_jupyterlab_amd as pkg
@@ -126,6 +146,9 @@ def main():
     if args.conv_math:
         ops.set_conv_math(args.conv_math)
     conv_math = ops.get_conv_math()
+    if args.logmel_math:
+        ops.set_logmel_math(args.logmel_math)
+    logmel_math = ops.get_logmel_math()
     B = args.batch
     n_conv = 2 if args.arch == "simple" else 3
     sd = pkg.synth.make_state_dict(args.arch, seed=1234)
@@ -203,6 +226,45 @@ def main():
     ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events])    # [steps, 3] K1,K2,K3
     k1_ms, k2_ms, k3_ms = [float(v) for v in ms.mean(axis=0)]
 
+    # sustained leg: the same step back to back for >= sustained_s seconds (every rank runs it; rank 0 reports)
+    sustained = None
+    if args.sustained_s > 0:
+        n_sus = max(50, int(args.sustained_s / max(1e-5, elapsed / args.steps)) + 1)
+        ev_every = max(1, n_sus // 200)                       # events on ~200 of the steps
+        sus_events = []
+        fence()
+        t1 = time.perf_counter()
+        for k in range(n_sus):
+            if k % ev_every == 0:
+                e4 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                sus_events.append((k, e4))
+                step(e4)
+            else:
+                step()
+        fence()
+        sus_elapsed = time.perf_counter() - t1
+        half = [e for k, e in sus_events if k >= n_sus // 2]   # second half: the clock has settled
+        sms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in half])
+        sustained = {"seconds": sus_elapsed, "steps": n_sus, "clips_per_s_per_gpu": B * n_sus / sus_elapsed,
+                     "ms_per_step": 1e3 * sus_elapsed / n_sus,
+                     "kernel_ms_second_half": dict(zip(["K1", "K2", "K3"], [float(v) for v in sms.mean(axis=0)])),
+                     "note": "host-timed, barrier + synchronize on both sides, same step as the timed region"}
+
+    # the float64 log-mel kernel on the whole batch (what auto mode costs per clip it redoes), outside the timed region
+    k1_f64_ms = None
+    if rank == 0:
+        ops.set_logmel_math("f64")
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for i in range(5):
+            if i == 2: evs[0].record(stream)
+            nat.check(nat.lib.ww_logmel_f32(p(pcm), B, 16000, 16000, 1, p(mel), st))
+        evs[1].record(stream)
+        torch.cuda.synchronize()
+        k1_f64_ms = evs[0].elapsed_time(evs[1]) / 3
+        ops.set_logmel_math(logmel_math)
+        nat.check(nat.lib.ww_logmel_f32(p(pcm), B, 16000, 16000, 1, p(mel), st))     # leave the measured mode's mel behind
+        torch.cuda.synchronize()
+
     # the exact-f32 MFMA conv kernel, timed outside the timed region for the second roofline line
     k2_f32_ms = None
     if rank == 0 and conv_math != "f32":
@@ -233,7 +295,7 @@ def main():
                             f"(K1 -> K2 -> K3{' -> RCCL all-gather of logits' if world > 1 else ''}), PCM and logits resident in HBM; "
                             + ("SimpleWakewordModel (train_wakeword.py:28-49)" if args.arch == "simple"
                                else "3-conv WakewordModel (wakeword_training_script.py:141-184)") + ", random-init weights seed 1234",
-                "global_batch": world * B, "clips_per_gpu": B, "conv_math": conv_math,
+                "global_batch": world * B, "clips_per_gpu": B, "conv_math": conv_math, "logmel_math": logmel_math,
                 "parallelism": f"clips sharded over {world} GPU(s), replicated weights",
             },
             "roofline": {
@@ -252,17 +314,26 @@ def main():
                 "K1_logmel": {"avg_ms": k1_ms, "bound": "hbm", "achieved_GBps": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / 1e9,
                               "peak_GBps": HBM_PEAK / 1e9, "frac": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / HBM_PEAK,
                               "clips_per_s": B / (k1_ms * 1e-3), "traffic": pmc_traffic("logmel_kernel", B, args.arch),
-                              "f32_vector_frac": K1_FLOPS_PER_CLIP * B / (k1_ms * 1e-3) / MFMA_F32_PEAK},
+                              "f32_vector_frac": K1_FLOPS_PER_CLIP * B / (k1_ms * 1e-3) / MFMA_F32_PEAK,
+                              "math": logmel_math + (" (float32 FFT kernel + the launch that redoes marked clips in float64; none of the "
+                                                     "benchmark's sine+noise clips is marked)" if logmel_math == "auto" else ""),
+                              "f64_mode_ms_whole_batch": k1_f64_ms},
                 "K2_cnn": {"avg_ms": k2_ms, "clips_per_s": B / (k2_ms * 1e-3)},
-                "K3_lstm_fc": {"avg_ms": k3_ms, "bound": "latency (one workgroup's layer 0 -> layer 1 -> fc chain; same time at 16 and 4096 clips)",
-                               "achieved_TFLOPs": K3_FLOPS_PER_CLIP[args.arch] * B / (k3_ms * 1e-3) / 1e12,
-                               "mfma": "v_mfma_f32_16x16x32_f16 x3 (split precision)" if conv_math == "f16x3" else "v_mfma_f32_16x16x4_f32",
-                               "mfma_f32_frac": K3_FLOPS_PER_CLIP[args.arch] * B / (k3_ms * 1e-3) / MFMA_F32_PEAK},
+                "K3_lstm_fc": dict({"avg_ms": k3_ms, "bound": "latency (one workgroup's layer 0 -> layer 1 -> fc chain; same time at 16 and 4096 clips)",
+                                    "achieved_TFLOPs": K3_FLOPS_PER_CLIP[args.arch] * B / (k3_ms * 1e-3) / 1e12,
+                                    "mfma": "v_mfma_f32_16x16x32_f16 x3 (split precision)" if split else "v_mfma_f32_16x16x4_f32",
+                                    # the gate GEMMs against the peak of the instruction they run on (algorithmic flops; x3 issued when split)
+                                    "mfma_frac_of_peak": K3_FLOPS_PER_CLIP[args.arch] * B / (k3_ms * 1e-3) / (MFMA_F16_PEAK if split else MFMA_F32_PEAK),
+                                    "mfma_peak_TFLOPs": (MFMA_F16_PEAK if split else MFMA_F32_PEAK) / 1e12},
+                                   **pmc_busy("lstm_fc", B, args.arch)),
                 "kernel_ms_sum": k1_ms + k2_ms + k3_ms,
             },
             "device": nat.device_info(),
             "sync_timeouts": int(nat.lib.ww_sync_timeouts()),      # bounded in-kernel waits that expired: must be 0
         }
+        if sustained is not None:
+            sustained["clips_per_s"] = sustained.pop("clips_per_s_per_gpu") * world
+            out["sustained"] = sustained
         if k2_f32_ms is not None:
             out["roofline_f32_exact"] = {
                 "kernel": "cnn2_kernel<POOL> (same stage with WW_CONV_MATH=f32: v_mfma_f32_32x32x2_f32, exact fp32)",
