@@ -39,6 +39,9 @@ def pack_with(h):
 hs, packs = [], []
 for path in libs:
     h = C.CDLL(path); h.ww_init(); hs.append(h); packs.append(pack_with(h))
+    import os
+    if os.environ.get("AB_LOGMEL_MATH") and hasattr(h, "ww_set_logmel_math"):      # 0 f32, 1 f64, 2 auto
+        assert h.ww_set_logmel_math(int(os.environ["AB_LOGMEL_MATH"])) == 0
     h.ww_cnn_scratch_bytes.restype = C.c_int64; h.ww_workspace_bytes.restype = C.c_int64
 scratch = torch.empty(max(1, max(h.ww_cnn_scratch_bytes(C.c_int64(B), C.c_int32(n_conv)) for h in hs)), dtype=torch.uint8, device=dev)
 ws = torch.empty(max(h.ww_workspace_bytes(C.c_int64(B), C.c_int32(n_conv)) for h in hs), dtype=torch.uint8, device=dev)

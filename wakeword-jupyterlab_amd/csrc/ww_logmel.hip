@@ -33,21 +33,30 @@ static_assert(kPartialInSlab + kPieces <= kSlab, "piece sums must fit behind the
 // WAVES = 4: the throughput form, three workgroups per CU, persistent over clips.
 // WAVES = 8: the latency form for batches of at most one clip per CU (streaming): a clip's 32 frames take 4 rounds
 //            instead of 8, one 83 KB workgroup per CU.
+// WW_K1_RESIDENT 1: the lane's 32 window values and 28 pass-1 twiddles live in registers for the life of the workgroup
+// (60 VGPRs) instead of being re-read through L1 for every frame; two waves per SIMD instead of three.
+// WW_K1_RESIDENT 2: also, a wave takes CONSECUTIVE frames of a clip and keeps the raw samples: frame t + 1 is frame t moved on
+// by 512 samples = two of the eight 256-sample groups, so six groups are register moves and only two are loaded.
+#ifndef WW_K1_RESIDENT
+#define WW_K1_RESIDENT 0
+#endif
 template <int WAVES>
 struct K1Layout {
     static constexpr int kWaves = WAVES;
     static constexpr int kThreads = WAVES * 64;
     static constexpr int kOffMel = WAVES * kSlab;
     static constexpr int kOffRed = kOffMel + kMels * kMelStride;
-    static constexpr int kOffFrm = kOffRed + 16;            // [2][WAVES][32] per-frame partial (energy, quietest live band): auto mode
-    static constexpr int kOffPinfo = kOffFrm + 2 * WAVES * 32;   // [kPieces] ints
+    static constexpr int kOffFrm = kOffRed + 16;            // auto mode: [WAVES][32] per-frame energy partials, [80] 1 / wmax_b, [4] redo flag
+    static constexpr int kOffInvw = kOffFrm + WAVES * 32;
+    static constexpr int kOffFlag = kOffInvw + kMels;
+    static constexpr int kOffPinfo = kOffFlag + 4;          // [kPieces] ints
     static constexpr int kOffFp0 = kOffPinfo + kPieces;     // [80] ints
     static constexpr int kOffFcnt = kOffFp0 + kMels;        // [80] ints
     static constexpr int kOffTw2 = kOffFcnt + kMels;        // [7][16] float2
     static constexpr int kOffTwp = kOffTw2 + 7 * 16 * 2;    // [512] float2
     static constexpr int kLdsFloats = kOffTwp + 512 * 2;
-    static constexpr int kWavesPerSimd = WAVES == 4 ? 3 : 2;   // launch bound: 3 x 4 waves or 1 x 8 waves per CU
-    static constexpr int kBlocksPerCu = WAVES == 4 ? 3 : 1;
+    static constexpr int kWavesPerSimd = WAVES == 4 ? (WW_K1_RESIDENT ? 2 : 3) : 2;   // launch bound: 3 (2) x 4 waves or 1 x 8 waves per CU
+    static constexpr int kBlocksPerCu = WAVES == 4 ? (WW_K1_RESIDENT ? 2 : 3) : 1;
     static_assert(kOffPinfo % 4 == 0 && kOffTw2 % 4 == 0 && kOffTwp % 2 == 0, "LDS table alignment");
     static_assert(kFrames % WAVES == 0 && WAVES <= 8, "frames are dealt to the waves in whole rounds; red[] holds 16 floats");
 };
@@ -126,10 +135,10 @@ __device__ __forceinline__ float absmax3(float a, float b, float m) {
 // range-checked.  Ring mode (streaming): sample i of the window lives at (pos + i) mod len.
 using u32x4_t = __attribute__((ext_vector_type(4))) unsigned int;
 
-template <bool RING>
+template <bool RING, int N0 = 0, int N1 = 8>
 __device__ __forceinline__ void load_frame(float4 (&sn)[8], __amdgpu_buffer_rsrc_t rsrc, int base, int ring_pos, int ring_len) {
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) {
+    for (int n1 = N0; n1 < N1; ++n1) {
         const int idx = base + 256 * n1;              // multiple of 4; may be negative or past the end
         int off = idx * 4;
         if constexpr (RING) {
@@ -173,7 +182,8 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
                                                              float* __restrict__ out, int mark) {
     using L = K1Layout<WAVES>;
     constexpr int kWavesPerBlock = WAVES, kThreads = L::kThreads;
-    constexpr int kOffMel = L::kOffMel, kOffRed = L::kOffRed, kOffFrm = L::kOffFrm, kOffPinfo = L::kOffPinfo, kOffFp0 = L::kOffFp0,
+    constexpr int kOffMel = L::kOffMel, kOffRed = L::kOffRed, kOffFrm = L::kOffFrm, kOffInvw = L::kOffInvw, kOffFlag = L::kOffFlag,
+                  kOffPinfo = L::kOffPinfo, kOffFp0 = L::kOffFp0,
                   kOffFcnt = L::kOffFcnt, kOffTw2 = L::kOffTw2, kOffTwp = L::kOffTwp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mel = lds + kOffMel;                                 // [80][33]
@@ -201,7 +211,9 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
     if (tid < kMels) {
         reinterpret_cast<int*>(lds)[kOffFp0 + tid] = tb->filt_p0[tid];
         reinterpret_cast<int*>(lds)[kOffFcnt + tid] = tb->filt_cnt[tid];
+        lds[kOffInvw + tid] = tb->band_bins[tid];                        // 1 / wmax_b
     }
+    if (tid < 4) reinterpret_cast<uint32_t*>(lds)[kOffFlag + tid] = 0u;
     for (int i = tid; i < 7 * 16 * 2; i += kThreads) lds[kOffTw2 + i] = (&tb->tw2[0][0].x)[i];
     for (int i = tid; i < 512 * 2; i += kThreads) lds[kOffTwp + i] = (&tb->twp[0].x)[i];
     const int ring_pos = RING ? *ring_pos_p : 0;
@@ -229,8 +241,21 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
         const float* base = pcm + int64_t(ok ? c : 0) * clip_stride;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, ok ? clip_bytes : 0u, 0x00020000);
     };
+    constexpr int kRounds = kFrames / kWavesPerBlock;
+#if WW_K1_RESIDENT == 2
+    const int frame0 = wave * kRounds;                 // this wave's frames: frame0 .. frame0 + kRounds - 1
+#else
+    const int frame0 = wave;                           // frames wave, wave + WAVES, ...
+#endif
     float4 sn[8];
-    load_frame<RING>(sn, clip_rsrc(blockIdx.x), wave * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
+    load_frame<RING>(sn, clip_rsrc(blockIdx.x), frame0 * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
+#if WW_K1_RESIDENT
+    float4 wres[8], t1res[7];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) wres[n1] = win4[64 * n1 + lane_id];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) t1res[k1 - 1] = tw1_4[(k1 - 1) * 64 + lane_id];
+#endif
 #pragma unroll 1
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs_cur = clip_rsrc(clip), rs_next = clip_rsrc(clip + int(gridDim.x));
@@ -238,14 +263,22 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
         // `sn` was prefetched: by the prologue for the first clip, by the previous clip's last frame otherwise
 
 #pragma unroll 1
-        for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
+        for (int round = 0; round < kRounds; ++round) {
+#if WW_K1_RESIDENT == 2
+            const int frame = frame0 + round;
+#else
             const int frame = round * kWavesPerBlock + wave;
+#endif
             // Opaque copy of the lane id: every swizzled LDS address below is a function of it.  Without this the
             // compiler hoists ~100 loop-invariant address VGPRs out of the frame loop and spills the prefetched samples.
             int lane = lane_id;
             asm volatile("" : "+v"(lane));
             const int k1r = lane >> 3, jr = lane & 7;                   // pass-2 role: (k1, j)
+#if WW_K1_RESIDENT == 2
+            const int base_next = (frame + 1) * kHop - kNfft / 2 + 4 * lane;
+#else
             const int base_next = (frame + kWavesPerBlock) * kHop - kNfft / 2 + 4 * lane;
+#endif
 
             STAMP(8);
             // ---- load + window: lane holds z[128 n1 + 2 lane + q], q = 0,1, n1 = 0..7 ----
@@ -253,7 +286,11 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
                 const float4 s = sn[n1];
+#if WW_K1_RESIDENT
+                const float4 w = wres[n1];
+#else
                 const float4 w = win4[64 * n1 + lane];
+#endif
                 // every sample sits in 4 frames; samples [512 t, 512 t + 512) = loads n1 4 and 5 of frame t tile the clip once
                 if (n1 == 4 || n1 == 5) peak = absmax3(s.z, s.w, absmax3(s.x, s.y, peak));
                 za[n1] = make_float2(s.x * w.x, s.y * w.y);
@@ -264,8 +301,12 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
             // is issued right there and the wave pays one L1 / LDS round trip per twiddle.
             float4 t1[7];
 #pragma unroll
+#if WW_K1_RESIDENT
+            for (int k1 = 1; k1 < 8; ++k1) t1[k1 - 1] = t1res[k1 - 1];
+#else
             for (int k1 = 1; k1 < 8; ++k1) t1[k1 - 1] = tw1_4[(k1 - 1) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
+#endif
             dft8(za);
             dft8(zb);
             slab4[lane] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
@@ -345,9 +386,17 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
             // next frame's samples: issued here, after the register-hungry FFT passes, and in flight under the
             // power / mel stages (about a third of the frame time, several times the HBM latency)
             {
-                const bool last = round + 1 == kFrames / kWavesPerBlock;            // uniform: descriptor select, no branch
-                load_frame<RING>(sn, last ? rs_next : rs_cur, last ? wave * kHop - kNfft / 2 + 4 * lane : base_next, ring_pos,
+                const bool last = round + 1 == kRounds;            // uniform: descriptor select, no branch
+#if WW_K1_RESIDENT == 2
+                // the next frame's groups 0..5 are this frame's 2..7; groups 6, 7 are new.  On the clip's last round these are
+                // the next clip's first frame's 6, 7 and its groups 0..5 are loaded behind the round loop.
+#pragma unroll
+                for (int n1 = 0; n1 < 6; ++n1) sn[n1] = sn[n1 + 2];
+                load_frame<RING, 6, 8>(sn, last ? rs_next : rs_cur, last ? frame0 * kHop - kNfft / 2 + 4 * lane : base_next, ring_pos, ring_len);
+#else
+                load_frame<RING>(sn, last ? rs_next : rs_cur, last ? frame0 * kHop - kNfft / 2 + 4 * lane : base_next, ring_pos,
                                  ring_len);
+#endif
             }
             // ---- real-input split + power: bins k = lane + 64 j and 1024 - k ----
             {
@@ -432,13 +481,27 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
             lds_order();   // the slab and `partial` are rewritten by the next frame
             STAMP(5);
         }
+#if WW_K1_RESIDENT == 2
+        load_frame<RING, 0, 6>(sn, rs_next, frame0 * kHop - kNfft / 2 + 4 * lane_id, ring_pos, ring_len);   // in flight under the epilogue
+#endif
         __syncthreads();   // all 32 frames' mel bands are in LDS
         STAMP(6);
 
         // ---- per-clip peak and mel max ----
-        float mmax = 0.f;
-        for (int idx = tid; idx < kMels * kFrames; idx += kThreads)
-            mmax = fmaxf(mmax, mel[(idx >> 5) * kMelStride + (idx & 31)]);
+        // auto mode rides on this pass: every idx of a thread belongs to frame tid & 31, so the thread also sums its share of
+        // the frame's energy estimate  E = sum_b P_b / wmax_b  (the triangles M_bk / wmax_b are a partition of unity over the bins)
+        float mmax = 0.f, e_part = 0.f;
+        const float* invw = lds + kOffInvw;
+        float* frm = lds + kOffFrm;
+        for (int idx = tid; idx < kMels * kFrames; idx += kThreads) {
+            const float p = mel[(idx >> 5) * kMelStride + (idx & 31)];
+            mmax = fmaxf(mmax, p);
+            if (mark) e_part = fmaf(p, invw[idx >> 5], e_part);
+        }
+        if (mark) {
+            e_part += __shfl_xor(e_part, 32);
+            if (lane < 32) frm[wave * 32 + lane] = e_part;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             mmax = fmaxf(mmax, __shfl_xor(mmax, off));
@@ -459,10 +522,16 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
         ref = ref < amin ? amin : ref;
         const float ref_db = db10(ref);
         float* __restrict__ o = out + int64_t(clip) * (kMels * kFrames);
-        // auto mode: per frame (= tid & 31 for every idx of this thread) the energy estimate sum_b P_b / wmax_b and the
-        // quietest live band min_b P_b / wmax_b; live = not clamped by top_db (with a 1 % margin) nor by amin
-        float e_part = 0.f, q_part = 3.0e38f;
+        // auto mode: a LIVE band (not clamped by top_db -- with a 1 % margin -- nor by amin) whose P_b / wmax_b lies below
+        // kFloorRatio * E of its frame sits on the float FFT's rounding floor: the clip is marked for the float64 kernel
+        float floor_e = 0.f;
+        if (mark) {
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) floor_e += frm[w * 32 + (tid & 31)];
+            floor_e *= kFloorRatio;
+        }
         const float live_thr = fmaxf(mmax * 0.99e-8f, amin / g2);
+        bool redo = false;
         for (int idx = tid; idx < kMels * kFrames; idx += kThreads) {
             const float p = mel[(idx >> 5) * kMelStride + (idx & 31)];
             float v = p * g2;
@@ -470,29 +539,15 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
             float db = db10(v) - ref_db;
             db = db < -80.0f ? -80.0f : db;
             o[idx] = db;
-            if (mark) {
-                const float u = p * tb->band_bins[idx >> 5];            // band_bins = 1 / wmax here (see ww_tables.cpp)
-                e_part += u;
-                q_part = p > live_thr ? fminf(q_part, u) : q_part;
-            }
+            if (mark) redo |= p > live_thr && p * invw[idx >> 5] < floor_e;     // false for NaN
         }
-        if (mark) {                                                     // uniform
-            float* frm = lds + kOffFrm;
-            e_part += __shfl_xor(e_part, 32);
-            q_part = fminf(q_part, __shfl_xor(q_part, 32));
-            if (lane < 32) { frm[wave * 32 + lane] = e_part; frm[(kWavesPerBlock + wave) * 32 + lane] = q_part; }
-            __syncthreads();
-            bool redo = false;
-            if (tid < 32) {
-                float e = 0.f, q = 3.0e38f;
-#pragma unroll
-                for (int w = 0; w < kWavesPerBlock; ++w) { e += frm[w * 32 + tid]; q = fminf(q, frm[(kWavesPerBlock + w) * 32 + tid]); }
-                redo = q < kFloorRatio * e;                             // false for NaN / empty frames
-            }
-            if (wave == 0 && __builtin_amdgcn_ballot_w64(redo) != 0ull && lane == 0)
-                reinterpret_cast<uint32_t*>(o)[0] = kRedoMark;          // after this thread's own store of o[0]
+        uint32_t* flag = reinterpret_cast<uint32_t*>(lds) + kOffFlag;
+        if (mark && __builtin_amdgcn_ballot_w64(redo) != 0ull && lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();   // mel / red / frm are rewritten by the next clip; the redo flag is complete
+        if (mark && tid == 0 && *flag) {                                    // after this thread's own store of o[0]
+            *flag = 0u;                                                     // the next clip's flag stores come behind its own barriers
+            reinterpret_cast<uint32_t*>(o)[0] = kRedoMark;
         }
-        __syncthreads();   // mel / red / frm are rewritten by the next clip
         STAMP(7);
     }
 #ifdef WW_STAMPS
