@@ -84,6 +84,11 @@ WW_API int ww_sync_timeouts(void);
  *                       from the clip's max |x| and the layers' l1 bounds, so no f16 half overflows or goes subnormal. */
 #define WW_CONV_MATH_F32 0
 #define WW_CONV_MATH_F16X3 1
+/*   WW_CONV_MATH_F16X3_DIRECT  F16X3 with every convolution in its direct (implicit-GEMM) form.  Under F16X3 the 2-conv model's
+ *                       conv2 -- 98 % of its flops -- runs as a one-dimensional Winograd F(2,3) along the image rows (1.5x
+ *                       fewer matrix instructions; the transforms are fp32 adds on the activations and exact-in-double
+ *                       combinations of the weights); the 3-conv model uses the direct form under both. */
+#define WW_CONV_MATH_F16X3_DIRECT 2
 WW_API int ww_set_conv_math(int mode);
 WW_API int ww_get_conv_math(void);
 

@@ -46,7 +46,7 @@ def _report():
             json.dump({"tolerance": LOGIT_TOL, "worst_logit_abs_err": _WORST, "max": max(_WORST.values())}, f, indent=1, sort_keys=True)
 
 
-@pytest.fixture(params=["f16x3", "f32"])
+@pytest.fixture(params=["f16x3", "f16x3d", "f32"])
 def conv_math(request):
     from wakeword_jupyterlab_amd import ops
     ops.set_conv_math(request.param)

@@ -27,9 +27,10 @@ def ops():
     return o
 
 
-@pytest.fixture(params=["f16x3", "f32"], autouse=True)
+@pytest.fixture(params=["f16x3", "f16x3d", "f32"], autouse=True)
 def conv_math(request, ops):
-    """Every test runs under both conv2 arithmetics: the default split-precision f16x3 kernels and the exact-f32 MFMA one."""
+    """Every test runs under all three conv arithmetics: the default split-precision f16x3 kernels (conv2 of the 2-conv model as 1-D
+    Winograd), f16x3 with every conv direct, and the exact-f32 MFMA kernels."""
     ops.set_conv_math(request.param)
     yield request.param
     ops.set_conv_math("f16x3")

@@ -131,6 +131,16 @@ def test_packed_weight_image_layout(arch):
         c = 16 * nt + (lane & 15)
         want = w_ih[col_row[c], 32 * kb + 8 * (lane >> 4) + j] * 2.0 ** S[c]
         assert np.abs((lh[layer][:, :, 0] + lh[layer][:, :, 1]) - want).max() <= 2.0 ** 13 * 2.0 ** -21
+    # conv2 in 1-D Winograd F(2,3) form along the rows: U0 = w[dy=0], U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w[dy=2];
+    # [nt16][ks = xi*3 + dx][hi/lo][lane][j], one scale per output channel over all four xi
+    hw = take(4 * 12 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(4, 4, 3, 2, 64, 8)      # [nt][xi][dx][hi/lo][lane][j]
+    U = np.stack([w2[:, :, 0, :], 0.5 * (w2[:, :, 0, :] + w2[:, :, 1, :] + w2[:, :, 2, :]),
+                  0.5 * (w2[:, :, 0, :] - w2[:, :, 1, :] + w2[:, :, 2, :]), w2[:, :, 2, :]], axis=2)     # [co][ci][xi][dx]
+    Sw = row_exps(take(64), U.reshape(64, -1))
+    nt, xi, dx, lane, j = np.meshgrid(np.arange(4), np.arange(4), np.arange(3), np.arange(64), np.arange(8), indexing="ij")
+    co = 16 * nt + (lane & 15)
+    wantw = U[co, 8 * (lane >> 4) + j, xi, dx] * 2.0 ** Sw[co]
+    assert np.abs((hw[:, :, :, 0] + hw[:, :, :, 1]) - wantw).max() <= 2.0 ** 13 * 2.0 ** -21
     # range bounds for the per-clip activation exponents: |conv_l out| <= max|in| * l1[l] + max|b_l|
     rng = take(8)
     for li, (l1, bm) in enumerate([(rng[0], rng[1]), (rng[2], rng[3])], start=1):

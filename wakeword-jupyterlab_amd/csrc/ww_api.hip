@@ -188,7 +188,8 @@ static int streamer_enqueue(ww_streamer* s, const float* hop_dev, float* prob_de
 extern "C" {
 
 int ww_set_conv_math(int mode) {
-    if (mode != WW_CONV_MATH_F32 && mode != WW_CONV_MATH_F16X3) return fail(WW_EINVAL, "unknown conv math mode %d", mode);
+    if (mode != WW_CONV_MATH_F32 && mode != WW_CONV_MATH_F16X3 && mode != WW_CONV_MATH_F16X3_DIRECT)
+        return fail(WW_EINVAL, "unknown conv math mode %d", mode);
     set_conv_math_mode(mode);
     return WW_OK;
 }

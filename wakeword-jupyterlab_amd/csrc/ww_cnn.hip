@@ -734,6 +734,261 @@ extern "C" __attribute__((visibility("default"))) int ww_debug_cnn_stamps(unsign
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// cnn2w_kernel: conv1 + conv2 + ReLU + pool with conv2 as a ONE-DIMENSIONAL WINOGRAD F(2,3) along the image rows
+// (split precision, v_mfma_f32_16x16x32_f16 x3): two output rows (2t, 2t+1) of a "tile row" t come from the four
+// conv1 rows d0..d3 = 2t-1 .. 2t+2 as
+//     V0 = d0 - d2,  V1 = d1 + d2,  V2 = d2 - d1,  V3 = d1 - d3                        (producers, fp32, per lane)
+//     M_xi = sum_{dx, ci} V_xi[x + dx - 1][ci] * U_xi[dx][ci][co]                       (consumers, matrix cores)
+//         U0 = w[dy=0],  U1 = (w0 + w1 + w2)/2,  U2 = (w0 - w1 + w2)/2,  U3 = w[dy=2]    (host, double)
+//     out[2t] = M0 + M1 + M2,   out[2t+1] = M1 - M2 - M3
+// 12 instead of 18 MFMA triples per (two output rows, column half, N-tile): 1.5x fewer matrix-pipe cycles than the
+// direct form, which is bound by them.  The transform runs ALONG ROWS so that it is pure per-lane arithmetic in the
+// producers (a lane holds one column) and the consumers keep only one tile row's eight accumulators live (B operands
+// 96 + accumulators 32 VGPRs); the column direction stays a direct 3-tap convolution through shifted fragment addresses.
+// The errors are those of fp32 adds on the activations (no cancellation beyond one subtraction) -- tested like the
+// direct form against the float64 oracle.
+// 12 waves per workgroup, one per CU:
+//   waves 8-11  PRODUCERS: wave pw makes tile rows t = pw (mod 4): its four conv1 rows on the matrix cores (each row is
+//               computed by two producers; no data passes between producer waves), 2*relu, transform, hi/lo split, one
+//               record per (xi, column) into a ring of 6 tile-row buffers in LDS;
+//   waves 0-7   CONSUMERS = (N-tile of 16 channels) x (tile-row parity): 24 fragment steps x 3 MFMAs per tile row.
+// Synchronisation: per ring buffer a FULL counter (producer -> consumers) and a FREE counter (4 consumer waves ->
+// producer), monotonic, bounded polls, poisoning as in cnn2h16_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWTileRows = kH / 2;                  // 40
+constexpr int kWRec = 160;                          // [32 ci hi][32 ci lo][32 B pad]: conflict-free 16x16x32 fragment reads
+constexpr int kWPlane = kRS * kWRec;                // one xi plane of a tile row: columns -1..32
+constexpr int kWBuf = 4 * kWPlane;                  // 21,760 B per tile row
+constexpr int kWNB = 6;                             // ring depth
+constexpr int kCWLds = kWNB * kWBuf + 4 * kMelHPlane * 2 + 2 * 8 * 16 * 4;
+static_assert(kWTileRows % 4 == 0 && kWTileRows % 2 == 0, "producers take t mod 4, consumers t mod 2, the same in every clip");
+
+__global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__ mel, int n, int width,
+                                                       const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
+                                                       const float* __restrict__ b1,
+                                                       const u32x4* __restrict__ wH, const float* __restrict__ hs,
+                                                       const float* __restrict__ b2, const float* __restrict__ rng,
+                                                       float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* act0 = ldsb;
+    _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + kWNB * kWBuf);      // 2 clips x (hi plane, lo plane) of [82][36] f16
+    float* red = reinterpret_cast<float*>(melh0 + 4 * kMelHPlane);           // [clip parity][8 consumer waves][16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 8;
+    const int nt = wave & 3, par = (wave >> 2) & 1;
+    const int pi = lane & 15, kq = lane >> 4;
+    const int ptid = tid - 512;
+
+    __shared__ uint32_t full_cnt[kWNB], free_cnt[kWNB], mel_done, xmax_done, clip_done[2], wg_bad;
+    __shared__ float xmaxw[2][4];
+    __shared__ float clip_par[2][2];
+    if (tid < kWNB) { full_cnt[tid] = 0u; free_cnt[tid] = 0u; }
+    if (tid == 0) { mel_done = 0u; xmax_done = 0u; clip_done[0] = 0u; clip_done[1] = 0u; wg_bad = 0u; }
+    for (int i = tid; i < kCWLds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;   // column halos / dead columns stay zero
+    __syncthreads();
+
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int steps = my_clips * kWTileRows;
+    const float half_inv_area = 0.5f / float(kH * width);
+
+    if (!consumer) {
+        // ================================================= producers =================================================
+        const int pw = wave - 8;
+        u32x4 w1h_r = w1H[lane], w1l_r = w1H[64 + lane];
+        asm volatile("" : "+v"(w1h_r), "+v"(w1l_r));
+        const half8 a1h = __builtin_bit_cast(half8, w1h_r), a1l = __builtin_bit_cast(half8, w1l_r);
+        const GatherLanes glanes = gather_lanes(lane & 31, lane >> 5);
+        __builtin_amdgcn_s_setprio(3);
+        const float rng_l1 = rng[0], rng_b1 = rng[1];
+        const int s1_exp = -exp_of(hs1[0]);
+        // model input of clip k -> two f16 planes of x * 2^-e (see cnn2h16_kernel).  All four producers meet inside (the xmax
+        // counter), which also tells each of them that nobody still reads the planes being overwritten.
+        auto load_mel = [&](int k, int& e_out, int& a_out) {
+            const float* __restrict__ src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kH * width;
+            _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
+            const int xx = ptid & 31, y0 = ptid >> 5;
+            const bool col_live = xx < width;
+            const float* __restrict__ sp = src + y0 * width + xx;
+            float v[10];
+            float mx = 0.f;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                v[t] = col_live ? sp[8 * t * width] : 0.f;
+                mx = fmaxf(mx, __builtin_fabsf(v[t]));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            if (lane == 0) xmaxw[k & 1][pw] = mx;
+            flag_signal(&xmax_done);
+            flag_wait(&xmax_done, 4u * unsigned(k + 1), &wg_bad);
+            mx = fmaxf(fmaxf(xmaxw[k & 1][0], xmaxw[k & 1][1]), fmaxf(xmaxw[k & 1][2], xmaxw[k & 1][3]));
+            const int e = clampi(exp_of(mx) - 14, -100, 113);
+            const float bound1 = fmaf(mx, rng_l1, rng_b1);
+            const int a = clampi(exp_of(bound1) - 12, -100, 100);       // |V| <= 2 * (2 relu): one more bit of headroom than the direct form
+            if (tid == 512) { clip_par[k & 1][0] = pow2i(a); clip_par[k & 1][1] = bound1; }
+            const float down = pow2i(-e);
+            if (col_live) {
+                _Float16* dh = ph + (y0 + 1) * kMelHRS + xx + 1;
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    const float vv = v[t] * down;
+                    const _Float16 hi = static_cast<_Float16>(vv);
+                    dh[8 * t * kMelHRS] = hi;
+                    dh[8 * t * kMelHRS + kMelHPlane] = static_cast<_Float16>(vv - static_cast<float>(hi));
+                }
+            }
+            e_out = e;
+            a_out = a;
+        };
+        Conv1Scale cs;
+        auto set_conv1_scale = [&](int e, int a) {
+            const int c0 = 16 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cs.binit[j] = ldexpf(b1[c0 + j], s1_exp - e);
+            cs.sc = ldexpf(1.0f, e - a - s1_exp);
+        };
+        const int x = lane & 31, h = lane >> 5;
+        const bool col_ok = x < width;
+        // 2 relu(conv1) * 2^-a of image row y (zero outside the image) for this lane's column and 16 channels
+        auto conv1_pair = [&](const _Float16* plane, int ya, f32x16& ra, f32x16& rb) {      // rows ya and ya + 1, side by side
+            const bool va = ya >= 0 && ya < kH, vb = ya + 1 >= 0 && ya + 1 < kH;
+            Conv1Row r0, r1;
+            if (va) conv1_row_gather(r0, plane, glanes, ya);
+            if (vb) conv1_row_gather(r1, plane, glanes, ya + 1);
+            if (va) conv1_row_mfma(r0, a1h, a1l, cs);
+            if (vb) conv1_row_mfma(r1, a1h, a1l, cs);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                ra[j] = va ? relu2(r0.acc[j] * cs.sc) : 0.f;
+                rb[j] = vb ? relu2(r1.acc[j] * cs.sc) : 0.f;
+            }
+        };
+        auto store16 = [&](const f32x16& v, char* rec) {
+#pragma unroll
+            for (int g8 = 0; g8 < 2; ++g8) {
+                u32x4 vh, vl;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t hh, ll;
+                    split2(v[8 * g8 + 2 * d], v[8 * g8 + 2 * d + 1], hh, ll);
+                    vh[d] = hh;
+                    vl[d] = ll;
+                }
+                *reinterpret_cast<u32x4*>(rec + g8 * 16) = vh;
+                *reinterpret_cast<u32x4*>(rec + 64 + g8 * 16) = vl;
+            }
+        };
+        int e_nx = 0, a_nx = 0;
+        if (steps > 0) { load_mel(0, e_nx, a_nx); flag_signal(&mel_done); }
+        for (int u = pw; u < steps; u += 4) {
+            const int k = u / kWTileRows, t = u - k * kWTileRows;
+            if (t == pw) {                                   // this producer's first tile row of clip k
+                flag_wait(&mel_done, 4u * unsigned(k + 1), &wg_bad);
+                set_conv1_scale(e_nx, a_nx);
+                if (k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
+            }
+            const int b = u % kWNB;
+            flag_wait(&free_cnt[b], 4u * unsigned(u / kWNB), &wg_bad);        // the four consumer waves of this parity are done with u - 6
+            const _Float16* plane = melh0 + (k & 1) * 2 * kMelHPlane;
+            f32x16 d0, d1, d2, d3;
+            conv1_pair(plane, 2 * t - 1, d0, d1);
+            conv1_pair(plane, 2 * t + 1, d2, d3);
+            if (col_ok) {
+                char* rec = act0 + b * kWBuf + (x + 1) * kWRec + h * 32;
+                store16(d0 - d2, rec);
+                store16(d1 + d2, rec + kWPlane);
+                store16(d2 - d1, rec + 2 * kWPlane);
+                store16(d1 - d3, rec + 3 * kWPlane);
+            }
+            flag_signal(&full_cnt[b]);
+        }
+    } else {
+        // ================================================= consumers =================================================
+        half8 bh[12], bl[12];
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            bh[ks] = __builtin_bit_cast(half8, wH[((nt * 12 + ks) * 2 + 0) * 64 + lane]);
+            bl[ks] = __builtin_bit_cast(half8, wH[((nt * 12 + ks) * 2 + 1) * 64 + lane]);
+        }
+        const float bias = b2[16 * nt + pi];
+        const float descale = 0.5f * hs[16 * nt + pi];
+        float dsc = descale, pool = 0.f;
+        for (int u = par; u < steps; u += 2) {
+            const int k = u / kWTileRows, t = u - k * kWTileRows;
+            const int b = u % kWNB;
+            flag_wait(&full_cnt[b], unsigned(u / kWNB) + 1u, &wg_bad);
+            if (t == par) { dsc = descale * clip_par[k & 1][0]; pool = 0.f; }
+            const char* ap = act0 + b * kWBuf + pi * kWRec + kq * 16;
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[xi][c][j] = 0.f;
+            // 24 fragment steps it = dx*8 + c*4 + xi: consecutive steps hit different accumulators
+            auto frag = [&](int it, int half) -> half8 {
+                const int dx = it >> 3, c = (it >> 2) & 1, xi = it & 3;
+                return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + xi * kWPlane + (16 * c + dx) * kWRec + half * 64));
+            };
+            constexpr int PF = 2, RING = PF + 1;
+            half8 fh[RING], fl[RING];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) { fh[i] = frag(i, 0); fl[i] = frag(i, 1); }
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                if (it + PF < 24) { fh[(it + PF) % RING] = frag(it + PF, 0); fl[(it + PF) % RING] = frag(it + PF, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const half8 ah = fh[it % RING], al = fl[it % RING];
+                const int dx = it >> 3, c = (it >> 2) & 1, xi = it & 3;
+                const int ks = xi * 3 + dx;
+                acc[xi][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc[xi][c], 0, 0, 0);
+                acc[xi][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[xi][c], 0, 0, 0);
+                acc[xi][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[xi][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            flag_signal(&free_cnt[b]);                       // the buffer is free as soon as its fragments are in the accumulators
+            // output transform + bias + 2*relu + pool (D: lane & 15 = channel, register j <-> column 16 c + 4 kq + j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float m12 = acc[1][c][j] + acc[2][c][j], m1m2 = acc[1][c][j] - acc[2][c][j];
+                    const float y0 = acc[0][c][j] + m12, y1 = m1m2 - acc[3][c][j];
+                    const float v = relu2(fmaf(y0, dsc, bias)) + relu2(fmaf(y1, dsc, bias));
+                    pool += (width == kW || 16 * c + 4 * kq + j < width) ? v : 0.f;
+                }
+            if (t >= kWTileRows - 2) {                        // this wave's last tile row of the clip
+                float p2 = pool + __shfl_xor(pool, 16);
+                p2 += __shfl_xor(p2, 32);
+                float* rk = red + (k & 1) * 8 * 16;
+                if (lane < 16) rk[wave * 16 + lane] = p2;
+                // the last of the eight consumer waves to arrive writes the clip's pooled features
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                uint32_t old = 0u;
+                if (lane == 0) old = __hip_atomic_fetch_add(&clip_done[k & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old + 1u == 8u * unsigned(k / 2 + 1)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                    const int t_nt = lane >> 4, t_n = lane & 15;
+                    out[clip * 64 + lane] = (rk[t_nt * 16 + t_n] + rk[(4 + t_nt) * 16 + t_n]) * half_inv_area;
+                }
+            }
+        }
+    }
+    // an expired wait anywhere in this workgroup: poison everything it produced
+    __syncthreads();
+    if (__hip_atomic_load(&wg_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+        const float nan = __uint_as_float(0x7fc00000u);
+        for (int k = 0; k < my_clips; ++k)
+            if (tid < 64) out[(int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * 64 + tid] = nan;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv3 (64->128) + ReLU + pool for the 3-conv WakewordModel.  512 threads: wave = (K-half kh, N-tile nt);
 // the two K-halves of an N-tile are summed through LDS before bias/ReLU.  Band = 4 output rows.
 // in = relu(conv2) as [n][80][64][32]; out = pooled [n][128].
@@ -952,6 +1207,7 @@ static int opt_in_lds() {
     if (done[dev]) return WW_OK;
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                int(sizeof(float) * kC3LdsFloats)));
@@ -967,9 +1223,16 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
     if (int rc = opt_in_lds()) return rc;
     const int cus = device_cu_count();
     const int grid1 = int(n < cus ? n : cus);                  // persistent: one workgroup per CU
-    if (conv_math_mode() == 1) {                               // f16x3
+    if (conv_math_mode() != 0) {                               // f16x3
         const u32x4* w1h = reinterpret_cast<const u32x4*>(packed + L.conv1_h);
         const u32x4* w2h = reinterpret_cast<const u32x4*>(packed + L.conv2_h16);
+        if (n_conv == 2 && conv_math_mode() == 1) {            // conv2 as 1-D Winograd
+            hipLaunchKernelGGL(cnn2w_kernel, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
+                               packed + L.conv1_hs, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv2_hw),
+                               packed + L.conv2_hws, packed + L.conv2_b, packed + L.range, pooled);
+            WW_HIP(hipGetLastError());
+            return WW_OK;
+        }
         if (n_conv == 2) {
             hipLaunchKernelGGL(cnn2h16_kernel<true>, dim3(grid1), dim3(768), kC2h16Lds, stream, mel, int(n), width, w1h,
                                packed + L.conv1_hs, packed + L.conv1_b, w2h, packed + L.conv2_hs, packed + L.conv2_b,

@@ -306,7 +306,7 @@ int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_co
     if (n == 0) return WW_OK;
     const PackedLayout L = packed_layout(n_conv);
     const int grid = int((n + kClipsPerBlock - 1) / kClipsPerBlock);
-    if (conv_math_mode() == 1) {
+    if (conv_math_mode() != 0) {
         hipLaunchKernelGGL(lstm_fc_h_kernel, dim3(grid), dim3(512), 0, stream, pooled, int(n), L.c_last,
                            reinterpret_cast<const u32x4_t*>(packed + L.l0_h), packed + L.l0_b,
                            reinterpret_cast<const u32x4_t*>(packed + L.l1_h), packed + L.l1_b, packed + L.lstm_hs,

@@ -97,6 +97,8 @@ struct PackedLayout {
     int64_t l0_h;      // W_ih l0 split for v_mfma_f32_16x16x32_f16: [K/32][48 ntile][hi,lo][64 lanes][4 dwords], columns as l0_w
     int64_t l1_h;      // same for layer 1 (K = 256)
     int64_t lstm_hs;   // [2][768]: 2^-S per packed gate column, layer 0 then layer 1
+    int64_t conv2_hw;  // conv2 as 1-D Winograd F(2,3) along rows, split precision: [4 ntile][12 kstep = xi*3+dx][hi,lo][64 lanes][4 dwords]
+    int64_t conv2_hws; // [64]: 2^-S per output channel of the transformed weights
     int64_t range;     // [8]: l1 bound of conv1 (max over channels of sum |w|), max |b1|, the same for conv2, 0...
     int64_t total;
 };
@@ -119,7 +121,8 @@ void build_kaiser_best(float* out /*[32769]*/);
 int sync_timeouts(unsigned int* count);   // bounded LDS-counter waits that expired (must be 0)
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
                     float* pooled, hipStream_t stream);
-// conv math: 0 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split (3 x v_mfma_f32_32x32x16_f16 per product block)
+// conv math: 0 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3 split (3 x v_mfma_f32_16x16x32_f16 per product block; conv2 of
+// the 2-conv model as 1-D Winograd), 2 = f16x3 split with every conv in its direct form
 int conv_math_mode();
 void set_conv_math_mode(int mode);
 int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_conv, float* logits,

@@ -187,6 +187,8 @@ PackedLayout packed_layout(int n_conv) {
     L.l0_h = take(int64_t(L.c_last / 32) * 48 * 2 * 64 * 4);
     L.l1_h = take(int64_t(kHidden / 32) * 48 * 2 * 64 * 4);
     L.lstm_hs = take(2 * kGateCols);
+    L.conv2_hw = take(4 * 12 * 2 * 64 * 4);
+    L.conv2_hws = take(64);
     L.range = take(8);
     L.total = o;
     return L;
@@ -271,6 +273,46 @@ static void pack_conv2_f16x3(const float* w, float* out_words16, float* descale)
                         const int64_t base = ((int64_t(nt) * 9 + ks) * 2) * 64 * 8;
                         o16b[base + lane * 8 + j] = hb;
                         o16b[base + 64 * 8 + lane * 8 + j] = lb;
+                    }
+            }
+}
+
+// conv2 weight [64][32][3][3] -> the 1-D Winograd F(2,3) form along the rows (dy), split precision, for cnn2w_kernel:
+//   U0 = w[dy=0], U1 = (w0 + w1 + w2)/2, U2 = (w0 - w1 + w2)/2, U3 = w[dy=2]   (per co, ci, dx; computed in double)
+// k-step ks = xi*3 + dx covers all 32 input channels; lane (n = lane&15, kq = lane>>4) holds
+// B[k = 8kq + j][n] = U_xi[dx][8kq + j][16*nt + n] * 2^S[co].  descale[64] = 2^-S per output channel (over all xi).
+static void pack_conv2_wino_f16x3(const float* w, float* out_words, float* descale) {
+    std::vector<double> U(size_t(64) * 32 * 4 * 3);          // [co][ci][xi][dx]
+    std::vector<int> S(64);
+    for (int co = 0; co < 64; ++co) {
+        double m = 0.0;
+        for (int ci = 0; ci < 32; ++ci)
+            for (int dx = 0; dx < 3; ++dx) {
+                const double w0 = w[((co * 32 + ci) * 3 + 0) * 3 + dx], w1 = w[((co * 32 + ci) * 3 + 1) * 3 + dx],
+                             w2 = w[((co * 32 + ci) * 3 + 2) * 3 + dx];
+                double* u = &U[((size_t(co) * 32 + ci) * 4) * 3 + dx];
+                u[0] = w0;
+                u[3] = 0.5 * (w0 + w1 + w2);
+                u[6] = 0.5 * (w0 - w1 + w2);
+                u[9] = w2;
+                for (int xi = 0; xi < 4; ++xi) m = std::fmax(m, std::fabs(u[3 * xi]));
+            }
+        S[co] = scale_exp(float(m) * 1.0000001f);
+        descale[co] = std::ldexp(1.0f, -S[co]);
+    }
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
+    for (int nt = 0; nt < 4; ++nt)
+        for (int xi = 0; xi < 4; ++xi)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ks = xi * 3 + dx;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 16 * nt + (lane & 15), ci = 8 * (lane >> 4) + j;
+                        uint16_t hb, lb;
+                        split_f16(std::ldexp(U[((size_t(co) * 32 + ci) * 4 + xi) * 3 + dx], S[co]), hb, lb);
+                        const int64_t base = ((int64_t(nt) * 12 + ks) * 2) * 64 * 8;
+                        o16[base + lane * 8 + j] = hb;
+                        o16[base + 64 * 8 + lane * 8 + j] = lb;
                     }
             }
 }
@@ -429,6 +471,7 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     if (sd->n_conv == 3) pack_conv3_f16x3(sd->conv_weight[2], out + L.conv3_h, out + L.conv3_hs);
     pack_conv1_f16x3(sd->conv_weight[0], out + L.conv1_h, out + L.conv1_hs);
     pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h16, out + L.conv2_hs);
+    pack_conv2_wino_f16x3(sd->conv_weight[1], out + L.conv2_hw, out + L.conv2_hws);
     pack_lstm_f16x3(sd->lstm_weight_ih[0], L.c_last, out + L.l0_h, out + L.lstm_hs);
     pack_lstm_f16x3(sd->lstm_weight_ih[1], kHidden, out + L.l1_h, out + L.lstm_hs + kGateCols);
     // range bounds for the per-clip activation exponents of the f16x3 kernels: |conv_l out| <= max|in| * l1[l] + bmax[l]

@@ -233,12 +233,13 @@ def forward_pcm(pcm, packed, n_conv, normalize: bool = True):
     return torch.ops.wakeword_amd.forward_pcm(pcm, packed, n_conv, normalize)
 
 
-CONV_MATH = {"f32": 0, "f16x3": 1}
+CONV_MATH = {"f32": 0, "f16x3": 1, "f16x3d": 2}
 
 
 def set_conv_math(mode: str) -> None:
-    """Arithmetic of the conv2 implicit GEMM, process-wide: 'f32' (exact fp32 MFMA) or 'f16x3' (each fp32 operand as
-    two f16 halves, three f16 MFMAs per product block, fp32 accumulate; ~2^-21 relative error, 3/16 the MFMA cycles)."""
+    """Arithmetic of the conv / LSTM-gate GEMMs, process-wide: 'f32' (exact fp32 MFMA), 'f16x3' (each fp32 operand as two f16
+    halves, three f16 MFMAs per product block, fp32 accumulate; ~2^-21 relative error, 3/16 the MFMA cycles; the 2-conv model's
+    conv2 as a 1-D Winograd F(2,3)) or 'f16x3d' (f16x3 with every convolution in its direct form)."""
     if mode not in CONV_MATH:
         raise ValueError(f"conv math {mode!r}: expected one of {sorted(CONV_MATH)}")
     nat.check(nat.lib.ww_set_conv_math(CONV_MATH[mode]))
