@@ -287,12 +287,15 @@ __device__ __forceinline__ void conv1_row_mfma(Conv1Row& r, half8 a1h, half8 a1l
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-// x ~= hi + lo for two values at once: v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32
-// (2.5 VALU instructions per value instead of 6 for the scalar form; same round-to-nearest result)
+// x ~= hi + lo for two values at once: v_cvt_pk_f16_f32, two v_fma_mix_f32, v_cvt_pk_f16_f32
+// (2 VALU instructions per value instead of 6 for the scalar form; same round-to-nearest result)
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     const float2_t v = {a, b};
     const half2_t h = __builtin_convertvector(v, half2_t);
-    const half2_t l = __builtin_convertvector(v - __builtin_convertvector(h, float2_t), half2_t);
+    // a - float(hi) as one mixed-precision fma per value (v_fma_mix_f32 reads the f16 half directly, exact like the subtraction):
+    // 4 instructions per pair instead of 5 with a half-rate packed subtract (bit-identical, -3 % on the conv kernel)
+    const float2_t r = {__builtin_fmaf(static_cast<float>(h[0]), -1.0f, a), __builtin_fmaf(static_cast<float>(h[1]), -1.0f, b)};
+    const half2_t l = __builtin_convertvector(r, half2_t);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
 }
@@ -748,20 +751,25 @@ extern "C" __attribute__((visibility("default"))) int ww_debug_cnn_stamps(unsign
 // The errors are those of fp32 adds on the activations (no cancellation beyond one subtraction) -- tested like the
 // direct form against the float64 oracle.
 // 12 waves per workgroup, one per CU:
-//   waves 8-11  PRODUCERS: wave pw makes tile rows t = pw (mod 4): its four conv1 rows on the matrix cores (each row is
-//               computed by two producers; no data passes between producer waves), 2*relu, transform, hi/lo split, one
-//               record per (xi, column) into a ring of 6 tile-row buffers in LDS;
-//   waves 0-7   CONSUMERS = (N-tile of 16 channels) x (tile-row parity): 24 fragment steps x 3 MFMAs per tile row.
-// Synchronisation: per ring buffer a FULL counter (producer -> consumers) and a FREE counter (4 consumer waves ->
-// producer), monotonic, bounded polls, poisoning as in cnn2h16_kernel.
+//   waves 8-11  PRODUCERS: wave pw makes the ten CONSECUTIVE tile rows t = 10 pw .. 10 pw + 9 of every clip, so that two of a
+//               tile row's four conv1 rows are the previous tile row's (kept in registers) and every conv1 row is computed
+//               once: conv1 on the matrix cores, 2*relu, transform, hi/lo split, one record per (xi, column);
+//   waves 0-7   CONSUMERS = (N-tile of 16 channels) x (group g): group g takes the tile rows of producers 2g and 2g + 1,
+//               alternately (the pool is a sum over all positions: the order of the tile rows is free, and fixed);
+//               24 fragment steps x 3 MFMAs per tile row.
+// Each group has a ring of 3 tile-row buffers in LDS.  Synchronisation: per buffer a FULL counter (producer -> consumers)
+// and a FREE counter (4 consumer waves -> producer), monotonic, bounded polls, poisoning as in cnn2h16_kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int kWTileRows = kH / 2;                  // 40
 constexpr int kWRec = 160;                          // [32 ci hi][32 ci lo][32 B pad]: conflict-free 16x16x32 fragment reads
 constexpr int kWPlane = kRS * kWRec;                // one xi plane of a tile row: columns -1..32
 constexpr int kWBuf = 4 * kWPlane;                  // 21,760 B per tile row
-constexpr int kWNB = 6;                             // ring depth
+constexpr int kWRing = 3;                           // tile-row buffers per consumer group
+constexpr int kWNB = 2 * kWRing;
+constexpr int kWPerProd = kWTileRows / 4;           // 10 tile rows per producer and clip
+constexpr int kWPerGroup = kWTileRows / 2;          // 20 tile rows per consumer group and clip
 constexpr int kCWLds = kWNB * kWBuf + 4 * kMelHPlane * 2 + 2 * 8 * 16 * 4;
-static_assert(kWTileRows % 4 == 0 && kWTileRows % 2 == 0, "producers take t mod 4, consumers t mod 2, the same in every clip");
+static_assert(kWTileRows % 4 == 0, "four producers with equal shares");
 
 __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__ mel, int n, int width,
                                                        const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
@@ -777,7 +785,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 8;
-    const int nt = wave & 3, par = (wave >> 2) & 1;
+    const int nt = wave & 3, grp = (wave >> 2) & 1;
     const int pi = lane & 15, kq = lane >> 4;
     const int ptid = tid - 512;
 
@@ -851,20 +859,6 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
         };
         const int x = lane & 31, h = lane >> 5;
         const bool col_ok = x < width;
-        // 2 relu(conv1) * 2^-a of image row y (zero outside the image) for this lane's column and 16 channels
-        auto conv1_pair = [&](const _Float16* plane, int ya, f32x16& ra, f32x16& rb) {      // rows ya and ya + 1, side by side
-            const bool va = ya >= 0 && ya < kH, vb = ya + 1 >= 0 && ya + 1 < kH;
-            Conv1Row r0, r1;
-            if (va) conv1_row_gather(r0, plane, glanes, ya);
-            if (vb) conv1_row_gather(r1, plane, glanes, ya + 1);
-            if (va) conv1_row_mfma(r0, a1h, a1l, cs);
-            if (vb) conv1_row_mfma(r1, a1h, a1l, cs);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                ra[j] = va ? relu2(r0.acc[j] * cs.sc) : 0.f;
-                rb[j] = vb ? relu2(r1.acc[j] * cs.sc) : 0.f;
-            }
-        };
         auto store16 = [&](const f32x16& v, char* rec) {
 #pragma unroll
             for (int g8 = 0; g8 < 2; ++g8) {
@@ -882,27 +876,51 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
         };
         int e_nx = 0, a_nx = 0;
         if (steps > 0) { load_mel(0, e_nx, a_nx); flag_signal(&mel_done); }
-        for (int u = pw; u < steps; u += 4) {
-            const int k = u / kWTileRows, t = u - k * kWTileRows;
-            if (t == pw) {                                   // this producer's first tile row of clip k
-                flag_wait(&mel_done, 4u * unsigned(k + 1), &wg_bad);
-                set_conv1_scale(e_nx, a_nx);
-                if (k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
+        const int pgrp = pw >> 1, podd = pw & 1;
+        f32x16 d0, d1, d2, d3;                                // 2 relu(conv1) * 2^-a of image rows 2t-1 .. 2t+2
+        // one conv1 row (zero outside the image: a clamped row times 0 -- conv2's zero padding; a NaN there can only meet outputs
+        // that already see it through the image row itself)
+        auto conv1_rows2 = [&](const _Float16* plane, int ya, f32x16& ra, f32x16& rb) {    // rows ya, ya + 1: stage by stage
+            Conv1Row r0, r1;
+            const bool va = unsigned(ya) < unsigned(kH), vb = unsigned(ya + 1) < unsigned(kH);
+            conv1_row_gather(r0, plane, glanes, va ? ya : (ya < 0 ? 0 : kH - 1));
+            conv1_row_gather(r1, plane, glanes, vb ? ya + 1 : (ya + 1 < 0 ? 0 : kH - 1));
+            conv1_row_mfma(r0, a1h, a1l, cs);
+            conv1_row_mfma(r1, a1h, a1l, cs);
+            const float sa = va ? cs.sc : 0.f, sb = vb ? cs.sc : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                ra[j] = relu2(r0.acc[j] * sa);
+                rb[j] = relu2(r1.acc[j] * sb);
             }
-            const int b = u % kWNB;
-            flag_wait(&free_cnt[b], 4u * unsigned(u / kWNB), &wg_bad);        // the four consumer waves of this parity are done with u - 6
+        };
+        for (int k = 0; k < my_clips; ++k) {
+            flag_wait(&mel_done, 4u * unsigned(k + 1), &wg_bad);              // the clip's planes are complete
+            set_conv1_scale(e_nx, a_nx);
+            if (k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
             const _Float16* plane = melh0 + (k & 1) * 2 * kMelHPlane;
-            f32x16 d0, d1, d2, d3;
-            conv1_pair(plane, 2 * t - 1, d0, d1);
-            conv1_pair(plane, 2 * t + 1, d2, d3);
-            if (col_ok) {
-                char* rec = act0 + b * kWBuf + (x + 1) * kWRec + h * 32;
-                store16(d0 - d2, rec);
-                store16(d1 + d2, rec + kWPlane);
-                store16(d2 - d1, rec + 2 * kWPlane);
-                store16(d1 - d3, rec + 3 * kWPlane);
+#pragma unroll 1
+            for (int i = 0; i < kWPerProd; ++i) {
+                const int t = kWPerProd * pw + i;
+                const int q = k * kWPerGroup + 2 * i + podd;                  // position in the group's sequence of tile rows
+                const int b = pgrp * kWRing + q % kWRing;
+#ifndef WW_ABL_NOPROD          // timing-only ablation: consumers alone (results are garbage)
+                if (i == 0) conv1_rows2(plane, 2 * t - 1, d0, d1);
+                else { d0 = d2; d1 = d3; }                                    // rows 2t-1, 2t are the previous tile row's 2t'+1, 2t'+2
+                conv1_rows2(plane, 2 * t + 1, d2, d3);
+#endif
+                flag_wait(&free_cnt[b], 4u * unsigned(q / kWRing), &wg_bad);  // the group's four waves are done with the buffer's previous tile row
+#ifndef WW_ABL_NOPROD
+                if (col_ok) {
+                    char* rec = act0 + b * kWBuf + (x + 1) * kWRec + h * 32;
+                    store16(d0 - d2, rec);
+                    store16(d1 + d2, rec + kWPlane);
+                    store16(d2 - d1, rec + 2 * kWPlane);
+                    store16(d1 - d3, rec + 3 * kWPlane);
+                }
+#endif
+                flag_signal(&full_cnt[b]);
             }
-            flag_signal(&full_cnt[b]);
         }
     } else {
         // ================================================= consumers =================================================
@@ -915,11 +933,12 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
         const float bias = b2[16 * nt + pi];
         const float descale = 0.5f * hs[16 * nt + pi];
         float dsc = descale, pool = 0.f;
-        for (int u = par; u < steps; u += 2) {
-            const int k = u / kWTileRows, t = u - k * kWTileRows;
-            const int b = u % kWNB;
-            flag_wait(&full_cnt[b], unsigned(u / kWNB) + 1u, &wg_bad);
-            if (t == par) { dsc = descale * clip_par[k & 1][0]; pool = 0.f; }
+        const int gsteps = my_clips * kWPerGroup;
+        for (int q = 0; q < gsteps; ++q) {
+            const int k = q / kWPerGroup, sq = q - k * kWPerGroup;
+            const int b = grp * kWRing + q % kWRing;
+            flag_wait(&full_cnt[b], unsigned(q / kWRing) + 1u, &wg_bad);
+            if (sq == 0) { dsc = descale * clip_par[k & 1][0]; pool = 0.f; }
             const char* ap = act0 + b * kWBuf + pi * kWRec + kq * 16;
             f32x4 acc[4][2];
 #pragma unroll
@@ -933,12 +952,20 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                 const int dx = it >> 3, c = (it >> 2) & 1, xi = it & 3;
                 return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + xi * kWPlane + (16 * c + dx) * kWRec + half * 64));
             };
-            constexpr int PF = 2, RING = PF + 1;
+#ifndef WW_WINO_PF
+#define WW_WINO_PF 2
+#endif
+            constexpr int PF = WW_WINO_PF, RING = PF + 1;
             half8 fh[RING], fl[RING];
 #pragma unroll
             for (int i = 0; i < PF; ++i) { fh[i] = frag(i, 0); fl[i] = frag(i, 1); }
+#ifdef WW_ABL_NOCONS           // timing-only ablation: producers alone
+            constexpr int kIts = 0;
+#else
+            constexpr int kIts = 24;
+#endif
 #pragma unroll
-            for (int it = 0; it < 24; ++it) {
+            for (int it = 0; it < kIts; ++it) {
                 if (it + PF < 24) { fh[(it + PF) % RING] = frag(it + PF, 0); fl[(it + PF) % RING] = frag(it + PF, 1); }
                 __builtin_amdgcn_sched_barrier(0);
                 const half8 ah = fh[it % RING], al = fl[it % RING];
@@ -960,7 +987,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                     const float v = relu2(fmaf(y0, dsc, bias)) + relu2(fmaf(y1, dsc, bias));
                     pool += (width == kW || 16 * c + 4 * kq + j < width) ? v : 0.f;
                 }
-            if (t >= kWTileRows - 2) {                        // this wave's last tile row of the clip
+            if (sq == kWPerGroup - 1) {                       // this wave's last tile row of the clip
                 float p2 = pool + __shfl_xor(pool, 16);
                 p2 += __shfl_xor(p2, 32);
                 float* rk = red + (k & 1) * 8 * 16;
