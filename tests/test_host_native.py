@@ -141,6 +141,15 @@ def test_packed_weight_image_layout(arch):
     co = 16 * nt + (lane & 15)
     wantw = U[co, 8 * (lane >> 4) + j, xi, dx] * 2.0 ** Sw[co]
     assert np.abs((hw[:, :, :, 0] + hw[:, :, :, 1]) - wantw).max() <= 2.0 ** 13 * 2.0 ** -21
+    if n_conv == 3:       # conv3 in the same form: 2 channel blocks, ks = (xi*3 + dx)*2 + cb
+        hw3 = take(8 * 24 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(8, 4, 3, 2, 2, 64, 8)   # [nt][xi][dx][cb][hi/lo][lane][j]
+        U3 = np.stack([w3[:, :, 0, :], 0.5 * (w3[:, :, 0, :] + w3[:, :, 1, :] + w3[:, :, 2, :]),
+                       0.5 * (w3[:, :, 0, :] - w3[:, :, 1, :] + w3[:, :, 2, :]), w3[:, :, 2, :]], axis=2)
+        Sw3 = row_exps(take(128), U3.reshape(128, -1))
+        nt, xi, dx, cb, lane, j = np.meshgrid(np.arange(8), np.arange(4), np.arange(3), np.arange(2), np.arange(64), np.arange(8), indexing="ij")
+        co = 16 * nt + (lane & 15)
+        want = U3[co, 32 * cb + 8 * (lane >> 4) + j, xi, dx] * 2.0 ** Sw3[co]
+        assert np.abs((hw3[:, :, :, :, 0] + hw3[:, :, :, :, 1]) - want).max() <= 2.0 ** 13 * 2.0 ** -21
     # range bounds for the per-clip activation exponents: |conv_l out| <= max|in| * l1[l] + max|b_l|
     rng = take(8)
     for li, (l1, bm) in enumerate([(rng[0], rng[1]), (rng[2], rng[3])], start=1):

@@ -771,12 +771,15 @@ constexpr int kWPerGroup = kWTileRows / 2;          // 20 tile rows per consumer
 constexpr int kCWLds = kWNB * kWBuf + 4 * kMelHPlane * 2 + 2 * 8 * 16 * 4;
 static_assert(kWTileRows % 4 == 0, "four producers with equal shares");
 
+// POOL: out = pooled [n][64].   !POOL (3-conv model): out = relu(conv2) as float32 [n][80 rows][32 columns][64 channels] (zero beyond
+// `width`) for cnn3w_kernel, and apow2[clip] = 2^a2, the exponent that kernel gives its transformed conv3 inputs.
+template <bool POOL>
 __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__ mel, int n, int width,
                                                        const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
                                                        const float* __restrict__ b1,
                                                        const u32x4* __restrict__ wH, const float* __restrict__ hs,
                                                        const float* __restrict__ b2, const float* __restrict__ rng,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ apow2) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* act0 = ldsb;
     _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + kWNB * kWBuf);      // 2 clips x (hi plane, lo plane) of [82][36] f16
@@ -938,7 +941,16 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             const int k = q / kWPerGroup, sq = q - k * kWPerGroup;
             const int b = grp * kWRing + q % kWRing;
             flag_wait(&full_cnt[b], unsigned(q / kWRing) + 1u, &wg_bad);
-            if (sq == 0) { dsc = descale * clip_par[k & 1][0]; pool = 0.f; }
+            if (sq == 0) {
+                dsc = descale * clip_par[k & 1][0];
+                pool = 0.f;
+                if constexpr (!POOL) {
+                    if (wave == 0 && lane == 0) {     // |V3| <= 2 max relu(conv2): one more bit of headroom than a plain split needs
+                        const float bound2 = fmaf(clip_par[k & 1][1], rng[2], rng[3]);
+                        apow2[int64_t(blockIdx.x) + int64_t(k) * gridDim.x] = pow2i(clampi(exp_of(bound2) - 13, -100, 100));
+                    }
+                }
+            }
             const char* ap = act0 + b * kWBuf + pi * kWRec + kq * 16;
             f32x4 acc[4][2];
 #pragma unroll
@@ -978,16 +990,25 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             }
             flag_signal(&free_cnt[b]);                       // the buffer is free as soon as its fragments are in the accumulators
             // output transform + bias + 2*relu + pool (D: lane & 15 = channel, register j <-> column 16 c + 4 kq + j)
+            const int trow = kWPerProd * (2 * grp + (sq & 1)) + (sq >> 1);      // the tile row this step holds (producer 2 grp + (sq & 1), its i-th)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float m12 = acc[1][c][j] + acc[2][c][j], m1m2 = acc[1][c][j] - acc[2][c][j];
                     const float y0 = acc[0][c][j] + m12, y1 = m1m2 - acc[3][c][j];
-                    const float v = relu2(fmaf(y0, dsc, bias)) + relu2(fmaf(y1, dsc, bias));
-                    pool += (width == kW || 16 * c + 4 * kq + j < width) ? v : 0.f;
+                    const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
+                    const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
+                    if constexpr (POOL) {
+                        pool += col_live ? v0 + v1 : 0.f;
+                    } else {
+                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                        float* o = out + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + j) * 64 + 16 * nt + pi;
+                        o[0] = col_live ? 0.5f * v0 : 0.f;
+                        o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
+                    }
                 }
-            if (sq == kWPerGroup - 1) {                       // this wave's last tile row of the clip
+            if (POOL && sq == kWPerGroup - 1) {               // this wave's last tile row of the clip
                 float p2 = pool + __shfl_xor(pool, 16);
                 p2 += __shfl_xor(p2, 32);
                 float* rk = red + (k & 1) * 8 * 16;
@@ -1006,12 +1027,141 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             }
         }
     }
-    // an expired wait anywhere in this workgroup: poison everything it produced
+    // an expired wait anywhere in this workgroup: poison everything it produced (pooled features, or the conv3 scale)
     __syncthreads();
     if (__hip_atomic_load(&wg_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
         const float nan = __uint_as_float(0x7fc00000u);
-        for (int k = 0; k < my_clips; ++k)
-            if (tid < 64) out[(int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * 64 + tid] = nan;
+        for (int k = 0; k < my_clips; ++k) {
+            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+            if constexpr (POOL) { if (tid < 64) out[clip * 64 + tid] = nan; }
+            else { if (tid == 0) apow2[clip] = nan; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cnn3w_kernel: conv3 (64 -> 128) + ReLU + pool of the 3-conv WakewordModel as the same 1-D Winograd F(2,3) along the rows.
+// Input: relu(conv2) as float32 [row][column][64 channels] (cnn2w_kernel<false>).  8 waves = 8 N-tiles of 16 channels; a
+// wave's 192 B-operand VGPRs (24 k-steps = (xi, dx, channel block) x hi/lo) stay resident.  Per tile row the 512 threads
+// fetch the four input rows (one float4 = 4 channels of one column per thread and row), form V0..V3 in fp32, scale by the
+// clip's 2^-a2, split and write the [4 xi][34][64 hi | 64 lo] tile (288-byte records: conflict-free fragment reads) -- the
+// fetch is issued at the top of a step, transformed and written to the OTHER tile buffer behind the step's MFMAs.
+// 96 instead of 144 MFMA triples per (tile row, N-tile) of the direct form.
+// ------------------------------------------------------------------------------------------------
+constexpr int kW3Rec = 288;
+constexpr int kW3Plane = kRS * kW3Rec;              // 9,792
+constexpr int kW3Buf = 4 * kW3Plane;                // 39,168
+constexpr int kC3wLds = 2 * kW3Buf;
+
+__global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__ mid, const float* __restrict__ apow2, int n, int width,
+                                                       const u32x4* __restrict__ wH, const float* __restrict__ hs,
+                                                       const float* __restrict__ b3, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nt = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pi = lane & 15, kq = lane >> 4;
+
+    half8 bh[24], bl[24];
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) {
+        bh[ks] = __builtin_bit_cast(half8, wH[((nt * 24 + ks) * 2 + 0) * 64 + lane]);
+        bl[ks] = __builtin_bit_cast(half8, wH[((nt * 24 + ks) * 2 + 1) * 64 + lane]);
+    }
+    const float bias = b3[16 * nt + pi];
+    const float descale = 0.5f * hs[16 * nt + pi];          // this lane's output channel; the pool sums 2*relu
+    for (int i = tid; i < kC3wLds / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;   // column halos stay zero
+    __syncthreads();
+
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int steps = my_clips * kWTileRows;
+    const float inv_area = 1.0f / float(kH * width);
+    const int lx = tid >> 4, lcg = tid & 15;                 // loader role: column, group of 4 channels
+
+    float4 pre[4];
+    float pre_ap = 1.f;
+    auto fetch = [&](int g) {            // rows 2t-1 .. 2t+2 of step g (clip g / 40, tile row g % 40) -> registers
+        const int k = g / kWTileRows, t = g - k * kWTileRows;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const float* src = mid + (clip * kH * kW + lx) * 64 + 4 * lcg;
+        pre_ap = apow2[clip];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = 2 * t - 1 + i;
+            const bool ok = y >= 0 && y < kH;
+            const float4 v = *reinterpret_cast<const float4*>(src + int64_t(ok ? y : 0) * (kW * 64));
+            pre[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int g) {            // registers -> transform -> LDS tile g & 1
+        const float s = __uint_as_float(0x7f000000u - __float_as_uint(pre_ap));     // 2^-a2 (exact for a power of two; NaN stays NaN)
+        char* dst = ldsb + (g & 1) * kW3Buf + (lx + 1) * kW3Rec + lcg * 8;
+        auto put = [&](float4 v, char* rec) {
+            uint32_t h0, l0, h1, l1;
+            split2(v.x * s, v.y * s, h0, l0);
+            split2(v.z * s, v.w * s, h1, l1);
+            *reinterpret_cast<uint2*>(rec) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(rec + 128) = make_uint2(l0, l1);
+        };
+        const float4 d0 = pre[0], d1 = pre[1], d2 = pre[2], d3 = pre[3];
+        put(make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w), dst);
+        put(make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w), dst + kW3Plane);
+        put(make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w), dst + 2 * kW3Plane);
+        put(make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w), dst + 3 * kW3Plane);
+    };
+
+    if (steps > 0) { fetch(0); stash(0); }
+    __syncthreads();
+    float pool = 0.f, dsc = descale;
+    for (int g = 0; g < steps; ++g) {
+        const int k = g / kWTileRows, t = g - k * kWTileRows;
+        if (t == 0) {
+            dsc = descale * apow2[int64_t(blockIdx.x) + int64_t(k) * gridDim.x];    // the tile holds V * 2^-a2
+            pool = 0.f;
+        }
+        if (g + 1 < steps) fetch(g + 1);
+        const char* ap = ldsb + (g & 1) * kW3Buf + pi * kW3Rec + kq * 16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[xi][j] = 0.f;
+            // 24 fragment steps it = (dx*2 + cb)*4 + xi: consecutive steps hit different accumulators
+            auto frag = [&](int it, int half) -> half8 {
+                const int dx = it >> 3, cb = (it >> 2) & 1, xi = it & 3;
+                return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + xi * kW3Plane + (16 * c + dx) * kW3Rec + half * 128 + cb * 64));
+            };
+            half8 fh[2], fl[2];
+            fh[0] = frag(0, 0); fl[0] = frag(0, 1);
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                if (it + 1 < 24) { fh[(it + 1) & 1] = frag(it + 1, 0); fl[(it + 1) & 1] = frag(it + 1, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const half8 ah = fh[it & 1], al = fl[it & 1];
+                const int dx = it >> 3, cb = (it >> 2) & 1, xi = it & 3;
+                const int ks = (xi * 3 + dx) * 2 + cb;
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[xi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m12 = acc[1][j] + acc[2][j], m1m2 = acc[1][j] - acc[2][j];
+                const float y0 = acc[0][j] + m12, y1 = m1m2 - acc[3][j];
+                const float v = relu2(fmaf(y0, dsc, bias)) + relu2(fmaf(y1, dsc, bias));
+                pool += (width == kW || 16 * c + 4 * kq + j < width) ? v : 0.f;
+            }
+        }
+        if (t == kWTileRows - 1) {
+            float p2 = pool + __shfl_xor(pool, 16);
+            p2 += __shfl_xor(p2, 32);
+            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+            if (lane < 16) out[clip * 128 + 16 * nt + lane] = p2 * 0.5f * inv_area;
+        }
+        if (g + 1 < steps) stash(g + 1);     // the other buffer: last read in step g-1, retired by the barrier below
+        __syncthreads();
     }
 }
 
@@ -1234,7 +1384,9 @@ static int opt_in_lds() {
     if (done[dev]) return WW_OK;
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
-    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                int(sizeof(float) * kC3LdsFloats)));
@@ -1253,10 +1405,23 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
     if (conv_math_mode() != 0) {                               // f16x3
         const u32x4* w1h = reinterpret_cast<const u32x4*>(packed + L.conv1_h);
         const u32x4* w2h = reinterpret_cast<const u32x4*>(packed + L.conv2_h16);
-        if (n_conv == 2 && conv_math_mode() == 1) {            // conv2 as 1-D Winograd
-            hipLaunchKernelGGL(cnn2w_kernel, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
-                               packed + L.conv1_hs, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv2_hw),
-                               packed + L.conv2_hws, packed + L.conv2_b, packed + L.range, pooled);
+        if (conv_math_mode() == 1) {                           // conv2 (and conv3) as 1-D Winograd
+            const u32x4* w2w = reinterpret_cast<const u32x4*>(packed + L.conv2_hw);
+            if (n_conv == 2) {
+                hipLaunchKernelGGL(cnn2w_kernel<true>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
+                                   packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
+                                   packed + L.range, pooled, static_cast<float*>(nullptr));
+                WW_HIP(hipGetLastError());
+                return WW_OK;
+            }
+            float* apw = reinterpret_cast<float*>(static_cast<char*>(scratch) + mid_bytes(n));
+            hipLaunchKernelGGL(cnn2w_kernel<false>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
+                               packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
+                               packed + L.range, static_cast<float*>(scratch), apw);
+            WW_HIP(hipGetLastError());
+            hipLaunchKernelGGL(cnn3w_kernel, dim3(grid1), dim3(512), kC3wLds, stream, static_cast<const float*>(scratch),
+                               static_cast<const float*>(apw), int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_hw),
+                               packed + L.conv3_hws, packed + L.conv3_b, pooled);
             WW_HIP(hipGetLastError());
             return WW_OK;
         }

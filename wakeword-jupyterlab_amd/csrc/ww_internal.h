@@ -99,6 +99,8 @@ struct PackedLayout {
     int64_t lstm_hs;   // [2][768]: 2^-S per packed gate column, layer 0 then layer 1
     int64_t conv2_hw;  // conv2 as 1-D Winograd F(2,3) along rows, split precision: [4 ntile][12 kstep = xi*3+dx][hi,lo][64 lanes][4 dwords]
     int64_t conv2_hws; // [64]: 2^-S per output channel of the transformed weights
+    int64_t conv3_hw;  // (n_conv 3) conv3 in the same Winograd form: [8 ntile][24 kstep = (xi*3+dx)*2 + cb][hi,lo][64 lanes][4 dwords]
+    int64_t conv3_hws; // [128]
     int64_t range;     // [8]: l1 bound of conv1 (max over channels of sum |w|), max |b1|, the same for conv2, 0...
     int64_t total;
 };

@@ -189,6 +189,8 @@ PackedLayout packed_layout(int n_conv) {
     L.lstm_hs = take(2 * kGateCols);
     L.conv2_hw = take(4 * 12 * 2 * 64 * 4);
     L.conv2_hws = take(64);
+    L.conv3_hw = n_conv == 3 ? take(8 * 24 * 2 * 64 * 4) : -1;
+    L.conv3_hws = n_conv == 3 ? take(128) : -1;
     L.range = take(8);
     L.total = o;
     return L;
@@ -281,16 +283,18 @@ static void pack_conv2_f16x3(const float* w, float* out_words16, float* descale)
 //   U0 = w[dy=0], U1 = (w0 + w1 + w2)/2, U2 = (w0 - w1 + w2)/2, U3 = w[dy=2]   (per co, ci, dx; computed in double)
 // k-step ks = xi*3 + dx covers all 32 input channels; lane (n = lane&15, kq = lane>>4) holds
 // B[k = 8kq + j][n] = U_xi[dx][8kq + j][16*nt + n] * 2^S[co].  descale[64] = 2^-S per output channel (over all xi).
-static void pack_conv2_wino_f16x3(const float* w, float* out_words, float* descale) {
-    std::vector<double> U(size_t(64) * 32 * 4 * 3);          // [co][ci][xi][dx]
-    std::vector<int> S(64);
-    for (int co = 0; co < 64; ++co) {
+// Generalised over (cout, cin): cin / 32 channel blocks cb, k-step ks = (xi*3 + dx) * (cin/32) + cb  (conv3: 24 k-steps).
+static void pack_conv_wino_f16x3(const float* w, int cout, int cin, float* out_words, float* descale) {
+    std::vector<double> U(size_t(cout) * cin * 4 * 3);          // [co][ci][xi][dx]
+    std::vector<int> S(cout);
+    const int ncb = cin / 32;
+    for (int co = 0; co < cout; ++co) {
         double m = 0.0;
-        for (int ci = 0; ci < 32; ++ci)
+        for (int ci = 0; ci < cin; ++ci)
             for (int dx = 0; dx < 3; ++dx) {
-                const double w0 = w[((co * 32 + ci) * 3 + 0) * 3 + dx], w1 = w[((co * 32 + ci) * 3 + 1) * 3 + dx],
-                             w2 = w[((co * 32 + ci) * 3 + 2) * 3 + dx];
-                double* u = &U[((size_t(co) * 32 + ci) * 4) * 3 + dx];
+                const double w0 = w[((co * cin + ci) * 3 + 0) * 3 + dx], w1 = w[((co * cin + ci) * 3 + 1) * 3 + dx],
+                             w2 = w[((co * cin + ci) * 3 + 2) * 3 + dx];
+                double* u = &U[((size_t(co) * cin + ci) * 4) * 3 + dx];
                 u[0] = w0;
                 u[3] = 0.5 * (w0 + w1 + w2);
                 u[6] = 0.5 * (w0 - w1 + w2);
@@ -301,20 +305,21 @@ static void pack_conv2_wino_f16x3(const float* w, float* out_words, float* desca
         descale[co] = std::ldexp(1.0f, -S[co]);
     }
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < cout / 16; ++nt)
         for (int xi = 0; xi < 4; ++xi)
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ks = xi * 3 + dx;
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int co = 16 * nt + (lane & 15), ci = 8 * (lane >> 4) + j;
-                        uint16_t hb, lb;
-                        split_f16(std::ldexp(U[((size_t(co) * 32 + ci) * 4 + xi) * 3 + dx], S[co]), hb, lb);
-                        const int64_t base = ((int64_t(nt) * 12 + ks) * 2) * 64 * 8;
-                        o16[base + lane * 8 + j] = hb;
-                        o16[base + 64 * 8 + lane * 8 + j] = lb;
-                    }
-            }
+            for (int dx = 0; dx < 3; ++dx)
+                for (int cb = 0; cb < ncb; ++cb) {
+                    const int ks = (xi * 3 + dx) * ncb + cb;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 16 * nt + (lane & 15), ci = 32 * cb + 8 * (lane >> 4) + j;
+                            uint16_t hb, lb;
+                            split_f16(std::ldexp(U[((size_t(co) * cin + ci) * 4 + xi) * 3 + dx], S[co]), hb, lb);
+                            const int64_t base = ((int64_t(nt) * 12 * ncb + ks) * 2) * 64 * 8;
+                            o16[base + lane * 8 + j] = hb;
+                            o16[base + 64 * 8 + lane * 8 + j] = lb;
+                        }
+                }
 }
 
 // conv3 weight [128][64][3][3] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16:
@@ -471,7 +476,8 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     if (sd->n_conv == 3) pack_conv3_f16x3(sd->conv_weight[2], out + L.conv3_h, out + L.conv3_hs);
     pack_conv1_f16x3(sd->conv_weight[0], out + L.conv1_h, out + L.conv1_hs);
     pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h16, out + L.conv2_hs);
-    pack_conv2_wino_f16x3(sd->conv_weight[1], out + L.conv2_hw, out + L.conv2_hws);
+    pack_conv_wino_f16x3(sd->conv_weight[1], 64, 32, out + L.conv2_hw, out + L.conv2_hws);
+    if (sd->n_conv == 3) pack_conv_wino_f16x3(sd->conv_weight[2], 128, 64, out + L.conv3_hw, out + L.conv3_hws);
     pack_lstm_f16x3(sd->lstm_weight_ih[0], L.c_last, out + L.l0_h, out + L.lstm_hs);
     pack_lstm_f16x3(sd->lstm_weight_ih[1], kHidden, out + L.l1_h, out + L.lstm_hs + kGateCols);
     // range bounds for the per-clip activation exponents of the f16x3 kernels: |conv_l out| <= max|in| * l1[l] + bmax[l]
