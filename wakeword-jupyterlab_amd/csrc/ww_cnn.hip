@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
         bl[ks] = __builtin_bit_cast(half8, wH[((nt * 24 + ks) * 2 + 1) * 64 + lane]);
     }
     const float bias = b3[16 * nt + pi];
-    const float descale = 0.5f * hs[16 * nt + pi];          // this lane's output channel; the pool sums 2*relu
+    const float descale = hs[16 * nt + pi];                 // this lane's output channel (the inputs are relu(conv2) itself, not 2*relu)
     for (int i = tid; i < kC3wLds / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;   // column halos stay zero
     __syncthreads();
 
@@ -1153,6 +1153,9 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
                 const float v = relu2(fmaf(y0, dsc, bias)) + relu2(fmaf(y1, dsc, bias));
                 pool += (width == kW || 16 * c + 4 * kq + j < width) ? v : 0.f;
             }
+            // the next tile row goes into the OTHER buffer (last read in step g-1) between the two column halves: its loads have
+            // landed by now, and this wave's transform + stores run under its SIMD sibling's MFMAs instead of in front of the barrier
+            if (c == 0 && g + 1 < steps) stash(g + 1);
         }
         if (t == kWTileRows - 1) {
             float p2 = pool + __shfl_xor(pool, 16);
@@ -1160,7 +1163,6 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
             const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
             if (lane < 16) out[clip * 128 + 16 * nt + lane] = p2 * 0.5f * inv_area;
         }
-        if (g + 1 < steps) stash(g + 1);     // the other buffer: last read in step g-1, retired by the barrier below
         __syncthreads();
     }
 }
