@@ -234,10 +234,8 @@ def test_state_dict_round_trip_and_repack_on_update(dev, golden_simple):
     assert np.abs(y2 - model_oracle.forward_np(golden_simple["x32"], sd2)).max() <= LOGIT_TOL
 
 
-def test_training_mode_and_cpu_inputs_fail_loudly(dev):
+def test_cpu_inputs_and_unsupported_shapes_fail_loudly(dev):
     m = pkg.SimpleWakewordModel().to(dev)
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 1, 80, 32, device=dev))                   # default training mode
     m.eval()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 1, 80, 32))

@@ -38,6 +38,25 @@ class StateDict(C.Structure):
     ]
 
 
+class TrainParams(C.Structure):
+    """struct ww_train_params: DEVICE pointers, torch layout."""
+    _fields_ = [
+        ("n_conv", C.c_int32), ("hidden", C.c_int32),
+        ("conv_weight", C.c_void_p * 3), ("conv_bias", C.c_void_p * 3),
+        ("lstm_weight_ih", C.c_void_p * 2), ("lstm_bias_ih", C.c_void_p * 2), ("lstm_bias_hh", C.c_void_p * 2),
+        ("fc_weight", C.c_void_p), ("fc_bias", C.c_void_p),
+    ]
+
+
+class TrainGrads(C.Structure):
+    """struct ww_train_grads: DEVICE output pointers."""
+    _fields_ = [
+        ("conv_weight", C.c_void_p * 3), ("conv_bias", C.c_void_p * 3),
+        ("lstm_weight_ih", C.c_void_p * 2), ("lstm_bias", C.c_void_p * 2),
+        ("fc_weight", C.c_void_p), ("fc_bias", C.c_void_p),
+    ]
+
+
 class ClipDesc(C.Structure):
     """struct ww_clip_desc (include/wakeword_amd.h)."""
     _fields_ = [
@@ -85,6 +104,12 @@ PROTOTYPES = {
     "ww_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ww_model_forward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_forward_pcm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ww_train_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "ww_train_forward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(TrainParams), C.c_float, C.c_float, C.c_uint64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "ww_train_backward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(TrainParams), C.c_void_p, C.c_void_p, C.POINTER(TrainGrads),
+                                        C.c_void_p]),
+    "ww_train_masks": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_streamer_create": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "ww_streamer_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_streamer_window": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1396,6 +1396,17 @@ static int opt_in_lds() {
     return WW_OK;
 }
 
+// training forward (ww_train.hip): conv1 + conv2 + ReLU in exact fp32, relu(conv2) kept as [n][80][64][32]
+int launch_cnn2_f32_mid(const float* mel, int64_t n, int width, const float* w1, const float* b1, const float* wB, const float* b2, float* mid,
+                        hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    const int64_t cus = device_cu_count();
+    const int grid2 = int(n < 2 * cus ? n : 2 * cus);
+    hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid2), dim3(256), sizeof(float) * kC2LdsFloats, stream, mel, int(n), width, w1, b1, wB, b2, mid);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
                     float* pooled, hipStream_t stream) {
     if (n == 0) return WW_OK;

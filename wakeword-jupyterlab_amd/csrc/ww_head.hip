@@ -41,10 +41,31 @@ constexpr int kClipsPerBlock = 16;
 // xs: LDS [16][xstride] activations (row = clip, permuted); wt: packed [K/16][768][16]; hb = this wave's hidden block of
 // 32 units = six 16x16 tiles (gate i,g,o x two halves).  Writes h[clip][perm16(32*hb + u)] into hout.
 // Weight loads run two 16-k groups ahead of the MFMAs.
-template <int K>
+// TRAIN: the gate activations sigma(g_i), tanh(g_g), sigma(g_o) and tanh(c) of every (clip, unit) go to `save` ([4][n][256], what the
+// backward pass needs) and the layer output is multiplied by the unit's dropout factor (0 or 1 / (1 - p); also saved).
+struct TrainSave {
+    float* gates;        // [4][n][256]
+    float* mask;         // [n][256]
+    int n, clip0;
+    float p;             // drop probability
+    uint32_t seed_lo, seed_hi, layer;
+};
+// counter-based keep / drop decision for (layer, clip, unit): splitmix64 finaliser of the key -> uniform in [0, 1)
+__device__ __forceinline__ float dropout_factor(const TrainSave& ts, int clip, int unit) {
+    if (ts.p <= 0.f) return 1.0f;
+    unsigned long long x = (static_cast<unsigned long long>(ts.seed_hi) << 32 | ts.seed_lo) + 0x9E3779B97F4A7C15ull * (1ull + ts.layer)
+                           + (static_cast<unsigned long long>(clip) << 20) + static_cast<unsigned long long>(unit);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    const float u = static_cast<float>(static_cast<uint32_t>(x >> 40)) * (1.0f / 16777216.0f);      // 24 bits
+    return u < ts.p ? 0.f : 1.0f / (1.0f - ts.p);
+}
+
+template <int K, bool TRAIN = false>
 __device__ __forceinline__ void lstm_layer(const float* __restrict__ xs, int xstride, const float* __restrict__ wt,
                                            const float* __restrict__ bias, int hb, int lane, float* __restrict__ hout,
-                                           int hstride) {
+                                           int hstride, const TrainSave* ts = nullptr) {
     const int col = lane & 15, kq = lane >> 4;
     f32x4 acc[3][2];
 #pragma unroll
@@ -91,8 +112,23 @@ __device__ __forceinline__ void lstm_layer(const float* __restrict__ xs, int xst
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int clip = 4 * kq + j;
-            const float c = sigmoidf_(acc[0][h][j] + b_i) * tanhf_(acc[1][h][j] + b_g);
-            hout[clip * hstride + ucol] = sigmoidf_(acc[2][h][j] + b_o) * tanhf_(c);
+            const float gi = sigmoidf_(acc[0][h][j] + b_i), gg = tanhf_(acc[1][h][j] + b_g), go = sigmoidf_(acc[2][h][j] + b_o);
+            const float tc = tanhf_(gi * gg);
+            float hv = go * tc;
+            if constexpr (TRAIN) {
+                const int gclip = ts->clip0 + clip, unit = 32 * hb + u;
+                if (gclip < ts->n) {
+                    const int64_t at = int64_t(gclip) * kHidden + unit, plane = int64_t(ts->n) * kHidden;
+                    const float m = dropout_factor(*ts, gclip, unit);
+                    ts->gates[at] = gi;
+                    ts->gates[plane + at] = gg;
+                    ts->gates[2 * plane + at] = go;
+                    ts->gates[3 * plane + at] = tc;
+                    ts->mask[at] = m;
+                    hv *= m;
+                }
+            }
+            hout[clip * hstride + ucol] = hv;
         }
     }
 }
@@ -139,6 +175,90 @@ __global__ __launch_bounds__(512) void lstm_fc_kernel(const float* __restrict__ 
             if (prob && cls == 1) prob[clip0 + clip] = 1.0f / (1.0f + expf(other - logit));   // softmax(logits)[1]
         }
     }
+}
+
+// Training-mode head (the reference's model.train() forward: nn.LSTM(dropout=p) between the layers and
+// nn.Dropout(p) before fc, train_wakeword.py:34-35,46-47): the exact-f32 kernel above, saving what the backward pass needs.
+// hd1 [n][256]: the dropped layer-1 output (fc's input).
+__global__ __launch_bounds__(512) void lstm_fc_train_kernel(const float* __restrict__ pooled, int n, int C,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                                            float* __restrict__ gates0, float* __restrict__ mask0, float* __restrict__ hd0,
+                                                            float* __restrict__ gates1, float* __restrict__ mask1, float* __restrict__ hd1,
+                                                            float p_lstm, float p_fc, uint32_t seed_lo, uint32_t seed_hi,
+                                                            float* __restrict__ logits) {
+    __shared__ __attribute__((aligned(16))) float xs[kClipsPerBlock * 132];
+    __shared__ __attribute__((aligned(16))) float h0[kClipsPerBlock * kHS];
+    __shared__ __attribute__((aligned(16))) float h1[kClipsPerBlock * kHS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int clip0 = blockIdx.x * kClipsPerBlock;
+    const int xstride = C + 4;
+    for (int i = tid; i < kClipsPerBlock * C; i += 512) {
+        const int r = i / C, k = i - r * C;
+        xs[r * xstride + perm16(k)] = (clip0 + r < n) ? pooled[int64_t(clip0 + r) * C + k] : 0.f;
+    }
+    __syncthreads();
+    const TrainSave t0{gates0, mask0, n, clip0, p_lstm, seed_lo, seed_hi, 0u};
+    const TrainSave t1{gates1, mask1, n, clip0, p_fc, seed_lo, seed_hi, 1u};
+    if (C == 64) lstm_layer<64, true>(xs, xstride, w0, b0, wave, lane, h0, kHS, &t0);
+    else lstm_layer<128, true>(xs, xstride, w0, b0, wave, lane, h0, kHS, &t0);
+    __syncthreads();
+    lstm_layer<kHidden, true>(h0, kHS, w1, b1, wave, lane, h1, kHS, &t1);
+    __syncthreads();
+    for (int i = tid; i < kClipsPerBlock * kHidden; i += 512) {          // the dropped activations, natural order
+        const int r = i >> 8, k = i & 255;
+        if (clip0 + r < n) {
+            hd0[int64_t(clip0 + r) * kHidden + k] = h0[r * kHS + perm16(k)];
+            hd1[int64_t(clip0 + r) * kHidden + k] = h1[r * kHS + perm16(k)];
+        }
+    }
+    {
+        const int o = tid >> 4, part = tid & 15, clip = o >> 1, cls = o & 1;
+        const float* hrow = h1 + clip * kHS;
+        const float* wrow = fcw + cls * kHidden;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = part * 16; k < part * 16 + 16; ++k) acc = fmaf(hrow[perm16(k)], wrow[k], acc);
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 8);
+        if (part == 0 && clip0 + clip < n) logits[int64_t(clip0 + clip) * 2 + cls] = acc + fcb[cls];
+    }
+}
+
+// W_ih [4H][K] + biases (torch layout, DEVICE memory: the weights change every optimiser step) -> the k-major packed image of
+// pack_lstm (ww_tables.cpp): wt[(kg * 768 + col) * 16 + slot], col = (hb*3 + gate)*32 + u, slot = (k & 3) * 4 + ((k & 15) >> 2).
+__global__ void pack_lstm_dev_kernel(const float* __restrict__ w_ih, const float* __restrict__ b_ih, const float* __restrict__ b_hh, int K,
+                                     float* __restrict__ wt, float* __restrict__ b) {
+    const int goff[3] = {0, 2 * kHidden, 3 * kHidden};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K * kGateCols; i += gridDim.x * blockDim.x) {
+        const int col = i / K, k = i - col * K;                       // consecutive threads read consecutive k of one row
+        const int hb = col / 96, g = (col % 96) / 32, u = col % 32, row = goff[g] + 32 * hb + u;
+        wt[(int64_t(k >> 4) * kGateCols + col) * 16 + ((k & 3) << 2 | ((k & 15) >> 2))] = w_ih[int64_t(row) * K + k];
+        if (k == 0) b[col] = b_ih[row] + b_hh[row];
+    }
+}
+
+int launch_lstm_fc_train(const float* pooled, int64_t n, int C, const float* w_ih0, const float* b_ih0, const float* b_hh0,
+                         const float* w_ih1, const float* b_ih1, const float* b_hh1, const float* fcw, const float* fcb,
+                         float* packed_ws /* (C + 256) * 768 + 2 * 768 floats */, float* gates0, float* mask0, float* hd0,
+                         float* gates1, float* mask1, float* hd1, float p_lstm, float p_fc, uint64_t seed, float* logits,
+                         hipStream_t stream) {
+    float* w0 = packed_ws;
+    float* b0 = w0 + int64_t(C) * kGateCols;
+    float* w1 = b0 + kGateCols;
+    float* b1 = w1 + int64_t(kHidden) * kGateCols;
+    hipLaunchKernelGGL(pack_lstm_dev_kernel, dim3(192), dim3(256), 0, stream, w_ih0, b_ih0, b_hh0, C, w0, b0);
+    hipLaunchKernelGGL(pack_lstm_dev_kernel, dim3(768), dim3(256), 0, stream, w_ih1, b_ih1, b_hh1, kHidden, w1, b1);
+    WW_HIP(hipGetLastError());
+    const int grid = int((n + kClipsPerBlock - 1) / kClipsPerBlock);
+    hipLaunchKernelGGL(lstm_fc_train_kernel, dim3(grid), dim3(512), 0, stream, pooled, int(n), C, w0, b0, w1, b1, fcw, fcb, gates0, mask0, hd0,
+                       gates1, mask1, hd1, p_lstm, p_fc, uint32_t(seed), uint32_t(seed >> 32), logits);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -130,6 +130,14 @@ void set_conv_math_mode(int mode);
 int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_conv, float* logits,
                    float* prob /*nullable*/, hipStream_t stream);
 
+// training step (ww_train.hip)
+int64_t train_workspace_bytes(int64_t n);
+int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
+                  float* logits, hipStream_t st);
+int train_masks(const void* workspace, int64_t n, float* mask0, float* mask1, hipStream_t st);
+int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
+                   const ww_train_grads* g, hipStream_t st);
+
 int require_gfx950();
 int device_cu_count();   // CUs of the current device (256 on MI355X); cached
 

@@ -233,6 +233,86 @@ def forward_pcm(pcm, packed, n_conv, normalize: bool = True):
     return torch.ops.wakeword_amd.forward_pcm(pcm, packed, n_conv, normalize)
 
 
+# ------------------------------------------------------------------------------------------------
+# training step (SimpleWakewordModel): train-mode forward + backward on the HIP kernels of csrc/ww_train.hip
+# ------------------------------------------------------------------------------------------------
+_TRAIN_KEYS = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias",
+               "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
+               "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1", "lstm.bias_hh_l1", "fc.weight", "fc.bias")
+
+
+def _train_params_struct(params):
+    c1w, c1b, c2w, c2b, wi0, _wh0, bi0, bh0, wi1, _wh1, bi1, bh1, fw, fb = params
+    tp = nat.TrainParams()
+    tp.n_conv, tp.hidden = 2, 256
+    tp.conv_weight[0], tp.conv_weight[1] = c1w.data_ptr(), c2w.data_ptr()
+    tp.conv_bias[0], tp.conv_bias[1] = c1b.data_ptr(), c2b.data_ptr()
+    tp.lstm_weight_ih[0], tp.lstm_weight_ih[1] = wi0.data_ptr(), wi1.data_ptr()
+    tp.lstm_bias_ih[0], tp.lstm_bias_ih[1] = bi0.data_ptr(), bi1.data_ptr()
+    tp.lstm_bias_hh[0], tp.lstm_bias_hh[1] = bh0.data_ptr(), bh1.data_ptr()
+    tp.fc_weight, tp.fc_bias = fw.data_ptr(), fb.data_ptr()
+    return tp
+
+
+class _TrainStep(torch.autograd.Function):
+    """logits = model(x) in train mode, with d loss / d parameters from the HIP backward kernels.  `x` gets no gradient (the
+    reference never asks for one)."""
+
+    @staticmethod
+    def forward(ctx, x, p_lstm, p_fc, seed, *params):
+        x = _check_x(x)
+        params = tuple(p.detach().contiguous() for p in params)
+        for p in params:
+            _require_cuda_f32(p, "parameter")
+        B, T = x.shape[0], x.shape[3]
+        if B == 0:
+            raise ValueError("empty training batch")
+        logits = torch.empty((B, 2), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            ws = torch.empty(nat.check(nat.lib.ww_train_workspace_bytes(B, 2)), device=x.device, dtype=torch.uint8)
+            tp = _train_params_struct(params)
+            nat.check(nat.lib.ww_train_forward_f32(_ptr(x), B, T, C.byref(tp), float(p_lstm), float(p_fc), int(seed) & (2 ** 64 - 1),
+                                                   _ptr(ws), _ptr(logits), _stream()))
+        ctx.save_for_backward(x, ws, *params)
+        _TrainStep.last_workspace = ws
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, ws, *params = ctx.saved_tensors
+        B, T = x.shape[0], x.shape[3]
+        dlogits = dlogits.contiguous().float()
+        grads = [torch.empty_like(p) for p in params]
+        grads[5].zero_()                    # weight_hh: h0 = 0, the gradient is exactly zero
+        grads[9].zero_()
+        tg = nat.TrainGrads()
+        tg.conv_weight[0], tg.conv_bias[0], tg.conv_weight[1], tg.conv_bias[1] = (g.data_ptr() for g in grads[:4])
+        tg.lstm_weight_ih[0], tg.lstm_bias[0] = grads[4].data_ptr(), grads[6].data_ptr()
+        tg.lstm_weight_ih[1], tg.lstm_bias[1] = grads[8].data_ptr(), grads[10].data_ptr()
+        tg.fc_weight, tg.fc_bias = grads[12].data_ptr(), grads[13].data_ptr()
+        with torch.cuda.device(x.device):
+            tp = _train_params_struct(params)
+            nat.check(nat.lib.ww_train_backward_f32(_ptr(x), B, T, C.byref(tp), _ptr(dlogits), _ptr(ws), C.byref(tg), _stream()))
+        grads[7].copy_(grads[6])            # d/d bias_hh == d/d bias_ih
+        grads[11].copy_(grads[10])
+        return (None, None, None, None, *grads)
+
+
+def train_forward(x, named_params: dict, p_lstm: float, p_fc: float, seed: int):
+    """x [B,1,80,T] + the module's parameters (reference key set) -> logits [B,2] with an autograd graph behind them."""
+    return _TrainStep.apply(x, p_lstm, p_fc, seed, *[named_params[k] for k in _TRAIN_KEYS])
+
+
+def train_last_masks(n: int):
+    """Dropout factors of the most recent training forward: (mask0 [n,256], mask1 [n,256]) -- tests replay them elsewhere."""
+    ws = _TrainStep.last_workspace
+    m0 = torch.empty((n, 256), device=ws.device, dtype=torch.float32)
+    m1 = torch.empty_like(m0)
+    with torch.cuda.device(ws.device):
+        nat.check(nat.lib.ww_train_masks(_ptr(ws), n, _ptr(m0), _ptr(m1), _stream()))
+    return m0, m1
+
+
 CONV_MATH = {"f32": 0, "f16x3": 1, "f16x3d": 2}
 
 
