@@ -112,8 +112,20 @@ __device__ __forceinline__ void lstm_layer(const float* __restrict__ xs, int xst
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int clip = 4 * kq + j;
-            const float gi = sigmoidf_(acc[0][h][j] + b_i), gg = tanhf_(acc[1][h][j] + b_g), go = sigmoidf_(acc[2][h][j] + b_o);
-            const float tc = tanhf_(gi * gg);
+            float gi, gg, go, tc;
+            if constexpr (TRAIN) {
+                // gradients multiply these by dlogits that nearly cancel over the batch: 1 - 2/(e^2x + 1) loses ~5 bits of tanh(x) near
+                // x = 0 (fine for the 1e-3 logit tolerance of inference, visible at 1e-4 in d fc.weight): the library functions here
+                gi = 1.0f / (1.0f + expf(-(acc[0][h][j] + b_i)));
+                gg = tanhf(acc[1][h][j] + b_g);
+                go = 1.0f / (1.0f + expf(-(acc[2][h][j] + b_o)));
+                tc = tanhf(gi * gg);
+            } else {
+                gi = sigmoidf_(acc[0][h][j] + b_i);
+                gg = tanhf_(acc[1][h][j] + b_g);
+                go = sigmoidf_(acc[2][h][j] + b_o);
+                tc = tanhf_(gi * gg);
+            }
             float hv = go * tc;
             if constexpr (TRAIN) {
                 const int gclip = ts->clip0 + clip, unit = 32 * hb + u;

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(256, 1) void conv2_dgrad_kernel(const float* __rest
 #pragma unroll
     for (int t = 0; t < 9; ++t) w1r[t] = w1[ci * 9 + t];
     const float b1r = b1[ci];
-    float dw1[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, db1 = 0.f;
+    // float64 accumulators: a conv1 weight gradient is a sum of ~10^5 products dz * mel per workgroup with heavy cancellation
+    // (mel ~ -35 +- 15 dB against a dz that sums to almost nothing); in float32 the order of summation alone moves it by 1e-4
+    double dw1[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, db1 = 0.;
     for (int i = tid; i < kDgLdsFloats; i += 256) lds[i] = 0.f;
 
     const int lco = tid >> 2, lcol = (tid & 3) * 8;          // loader role: 64 co x 4 threads x 8 columns
@@ -306,10 +308,10 @@ __global__ __launch_bounds__(256, 1) void conv2_dgrad_kernel(const float* __rest
                         z = fmaf(w1r[0], m0, z); z = fmaf(w1r[1], m1, z); z = fmaf(w1r[2], m2, z);
                         z = fmaf(w1r[3], m3, z); z = fmaf(w1r[4], m4, z); z = fmaf(w1r[5], m5, z);
                         z = fmaf(w1r[6], m6, z); z = fmaf(w1r[7], m7, z); z = fmaf(w1r[8], m8, z);
-                        const float dz = (z > 0.f && col < width) ? da : 0.f;
-                        dw1[0] = fmaf(dz, m0, dw1[0]); dw1[1] = fmaf(dz, m1, dw1[1]); dw1[2] = fmaf(dz, m2, dw1[2]);
-                        dw1[3] = fmaf(dz, m3, dw1[3]); dw1[4] = fmaf(dz, m4, dw1[4]); dw1[5] = fmaf(dz, m5, dw1[5]);
-                        dw1[6] = fmaf(dz, m6, dw1[6]); dw1[7] = fmaf(dz, m7, dw1[7]); dw1[8] = fmaf(dz, m8, dw1[8]);
+                        const double dz = (z > 0.f && col < width) ? double(da) : 0.0;
+                        dw1[0] = fma(dz, double(m0), dw1[0]); dw1[1] = fma(dz, double(m1), dw1[1]); dw1[2] = fma(dz, double(m2), dw1[2]);
+                        dw1[3] = fma(dz, double(m3), dw1[3]); dw1[4] = fma(dz, double(m4), dw1[4]); dw1[5] = fma(dz, double(m5), dw1[5]);
+                        dw1[6] = fma(dz, double(m6), dw1[6]); dw1[7] = fma(dz, double(m7), dw1[7]); dw1[8] = fma(dz, double(m8), dw1[8]);
                         db1 += dz;
                     }
                 }
@@ -318,21 +320,21 @@ __global__ __launch_bounds__(256, 1) void conv2_dgrad_kernel(const float* __rest
     }
     // the two column halves (lane ^ 32) and the two row groups, in fixed order -> this workgroup's partial
     __syncthreads();
-    float* red = xch;
+    double* red = reinterpret_cast<double*>(xch);            // [rg][h][10][32] doubles = 10 KB of the 32 KB exchange area
+    if (kh == 0) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) dw1[t] += __shfl_xor(dw1[t], 32);
-    db1 += __shfl_xor(db1, 32);
-    if (kh == 0 && h == 0) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) red[(rg * 10 + t) * 32 + ci] = dw1[t];
-        red[(rg * 10 + 9) * 32 + ci] = db1;
+        for (int t = 0; t < 9; ++t) red[((rg * 2 + h) * 10 + t) * 32 + ci] = dw1[t];
+        red[((rg * 2 + h) * 10 + 9) * 32 + ci] = db1;
     }
     __syncthreads();
     float* outp = partial + int64_t(blockIdx.x) * kDgPartial;
     if (tid < 32) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) outp[tid * 9 + t] = red[t * 32 + tid] + red[(10 + t) * 32 + tid];
-        outp[32 * 9 + tid] = red[9 * 32 + tid] + red[19 * 32 + tid];
+        for (int t = 0; t < 10; ++t) {
+            const double s = (red[(0 * 10 + t) * 32 + tid] + red[(1 * 10 + t) * 32 + tid]) + (red[(2 * 10 + t) * 32 + tid] + red[(3 * 10 + t) * 32 + tid]);
+            if (t < 9) outp[tid * 9 + t] = float(s);
+            else outp[32 * 9 + tid] = float(s);
+        }
     }
 }
 
