@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 clock the chip holds under load): clips/s and per-kernel means over that leg
   parity        max |err| of the measured path against that oracle on the sample
   augmentation  augment_audio on the GPU: clips/s for plans drawn like the reference, error vs the oracle
+  training      SURVEY 8(f).3: training step of SimpleWakewordModel at the same batch (train-mode forward + backward + Adam)
   streaming     BASELINE configs[4] (256 microphones, 10 ms hop, hipGraph replay per hop): p50/p99 hop latency, hops/s
                 (rank 0, N = 1 only; measured after the timed region)
 """
@@ -364,6 +365,9 @@ def main():
             # AudioProcessor.augment_audio on the GPU (training-side stage that feeds K1)
             import bench_augment
             out["augmentation"] = bench_augment.measure(batch=B, steps=5, check=4, device=dev.index)
+            # one training step of the same model (forward in train mode + backward + Adam)
+            import bench_train
+            out["training"] = bench_train.measure(batch=B, steps=5, device=dev.index)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

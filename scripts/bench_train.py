@@ -1,0 +1,58 @@
+"""one training step (train-mode forward + CrossEntropyLoss + backward) of SimpleWakewordModel on the HIP kernels.
+measure() is embedded in the bench line; run alone for a per-kernel split: python scripts/bench_train.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def measure(batch=4096, steps=5, device=0, cpu_sample=64):
+    import wakeword_jupyterlab_amd as pkg
+    from oracle import model_oracle
+    dev = torch.device("cuda", device)
+    sd = pkg.synth.make_state_dict("simple", seed=1234)
+    m = pkg.SimpleWakewordModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    x = (torch.randn(batch, 1, 80, 32, device=dev) * 15 - 35).clamp_(-80, 0)
+    y = torch.randint(0, 2, (batch,), device=dev)
+
+    def step():
+        opt.zero_grad()
+        loss = crit(m(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    # the same step in torch on the host CPU, on a small sample (context only)
+    ref = model_oracle.torch_module_from_state_dict(sd).train()
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    xc, yc = x[:cpu_sample].cpu(), y[:cpu_sample].cpu()
+    t1 = time.perf_counter()
+    for _ in range(2):
+        opt_r.zero_grad()
+        crit(ref(xc), yc).backward()
+        opt_r.step()
+    dt_cpu = (time.perf_counter() - t1) / 2
+    return {"workload": f"SimpleWakewordModel training step (train-mode forward with dropout 0.5/0.5 + CrossEntropyLoss + backward + Adam), "
+                        f"batch {batch}, log-mel inputs resident in HBM; exact fp32 kernels (csrc/ww_train.hip)",
+            "ms_per_step": dt * 1e3, "clips_per_s": batch / dt, "final_loss": float(loss.item()),
+            "cpu_torch_clips_per_s": cpu_sample / dt_cpu, "cpu_threads": int(torch.get_num_threads()), "cpu_sample": cpu_sample}
+
+
+if __name__ == "__main__":
+    print(measure())

@@ -370,54 +370,69 @@ __global__ void lstm_gates_bwd_kernel(const float* __restrict__ dhd, const float
     }
 }
 
-// out[j] = sum_b x[b][j] in a fixed order (bias gradients); one thread per column, 64 rows per step through LDS-free registers
-__global__ void colsum_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
+// out[j] = sum_b x[b][j] in a fixed order (bias gradients): 1024 threads = 64 columns x 16 row slices, slices summed through LDS
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ out) {
+    __shared__ float part[16][65];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int b = 0; b < rows; ++b) s += x[int64_t(b) * cols + j];
-    out[j] = s;
+    if (j < cols)
+        for (int b = sl; b < rows; b += 16) s += x[int64_t(b) * cols + j];
+    part[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && j < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][c];
+        out[j] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // C[M][N] = sum_k A(m,k) B(k,n) with general strides (the six small GEMMs of the head's backward: M*N*K <= 1.1e9).
-// 64x64 tiles, 256 threads x 4x4 outputs, K in steps of 16 through LDS; fp32 FMA, fixed order.
+// T x T tiles (T = 64: 4x4 outputs per thread; T = 32: 2x2, four times the workgroups for the K = batch weight-gradient GEMMs),
+// 256 threads, K in steps of 16 through LDS; fp32 FMA, fixed order.
 // ------------------------------------------------------------------------------------------------
+template <int T>
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B, int64_t sbk,
                                                     int64_t sbn, float* __restrict__ C, int64_t ldc, int M, int N, int K) {
-    __shared__ float As[16][65], Bs[16][65];
+    constexpr int R = T / 16;
+    __shared__ float As[16][T + 1], Bs[16][T + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    float acc[4][4] = {};
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    float acc[R][R] = {};
     for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
-            const int kk = i >> 6, mm = i & 63;                 // consecutive threads walk m (or n)
+        for (int i = threadIdx.x; i < 16 * T; i += 256) {
+            const int kk = i / T, mm = i - kk * T;              // consecutive threads walk m (or n)
             As[kk][mm] = (m0 + mm < M && k0 + kk < K) ? A[int64_t(m0 + mm) * sam + int64_t(k0 + kk) * sak] : 0.f;
             Bs[kk][mm] = (n0 + mm < N && k0 + kk < K) ? B[int64_t(k0 + kk) * sbk + int64_t(n0 + mm) * sbn] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
+            float a[R], b[R];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+            for (int i = 0; i < R; ++i) { a[i] = As[kk][ty * R + i]; b[i] = Bs[kk][tx * R + i]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < R; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (m0 + ty * 4 + i < M && n0 + tx * 4 + j < N) C[int64_t(m0 + ty * 4 + i) * ldc + n0 + tx * 4 + j] = acc[i][j];
+        for (int j = 0; j < R; ++j)
+            if (m0 + ty * R + i < M && n0 + tx * R + j < N) C[int64_t(m0 + ty * R + i) * ldc + n0 + tx * R + j] = acc[i][j];
 }
 
 static void sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int M, int N, int K,
                   hipStream_t st) {
-    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K);
+    if (int64_t(M) * N <= 512 * 512)     // few output tiles (the weight gradients, K = batch): small tiles, more workgroups
+        hipLaunchKernelGGL(sgemm_kernel<32>, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K);
+    else
+        hipLaunchKernelGGL(sgemm_kernel<64>, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K);
 }
 
 // gp[b][co] = dpooled[b][co] / (80 * width)
@@ -515,17 +530,17 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const int N = int(n), H = kHidden;
     // fc: dW = dlogits^T hd1, db = colsum(dlogits), dhd1 = dlogits W_fc
     sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, st, dlogits, N, 2, g->fc_bias);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, st, dlogits, N, 2, g->fc_bias);
     sgemm(dlogits, 2, 1, p->fc_weight, H, 1, w.dhd1, H, N, H, 2, st);
     // layer 1
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(1024), dim3(256), 0, st, w.dhd1, w.gates1, w.mask1, N, w.dg1);
     sgemm(w.dg1, 1, 4 * H, w.hd0, H, 1, g->lstm_weight_ih[1], H, 4 * H, H, N, st);             // [1024][256] = dg1^T hd0
-    hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(64), 0, st, w.dg1, N, 4 * H, g->lstm_bias[1]);
+    hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(1024), 0, st, w.dg1, N, 4 * H, g->lstm_bias[1]);
     sgemm(w.dg1, 4 * H, 1, p->lstm_weight_ih[1], H, 1, w.dhd0, H, N, H, 4 * H, st);            // [n][256] = dg1 W_ih_l1
     // layer 0
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(1024), dim3(256), 0, st, w.dhd0, w.gates0, w.mask0, N, w.dg0);
     sgemm(w.dg0, 1, 4 * H, w.pooled, 64, 1, g->lstm_weight_ih[0], 64, 4 * H, 64, N, st);       // [1024][64] = dg0^T pooled
-    hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(64), 0, st, w.dg0, N, 4 * H, g->lstm_bias[0]);
+    hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(1024), 0, st, w.dg0, N, 4 * H, g->lstm_bias[0]);
     sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], 64, 1, w.dpooled, 64, N, 64, 4 * H, st);      // [n][64] = dg0 W_ih_l0
     hipLaunchKernelGGL(scale_kernel, dim3(256), dim3(256), 0, st, w.dpooled, 1.0f / float(kTH * width), n * 64, w.gp);
     WW_HIP(hipGetLastError());
