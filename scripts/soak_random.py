@@ -21,7 +21,7 @@ while time.time() - t0 < args.seconds:
     arch = rng.choice(["simple", "simple", "full"])
     n = rng.choice([1, 2, 3, 17, 63, 64, 255, 256, 257, 300, 511, 777, 1024, 1500, 4096 if arch == "simple" else 900])
     width = rng.choice([32, 32, 32, 31, 17, 5])
-    ops.set_conv_math(rng.choice(["f16x3", "f16x3", "f32"]))
+    ops.set_conv_math(rng.choice(["f16x3", "f16x3", "f16x3d", "f32"]))
     m, sd = models[arch]
     x = torch.from_numpy((pkg.synth.normal(rng.randrange(1 << 20), n * 80 * width).astype(np.float32).reshape(n, 1, 80, width) * 15 - 35)).to(dev)
     with torch.no_grad():
