@@ -238,14 +238,14 @@ WW_API int ww_forward_pcm_f32(const float* pcm_dev, int64_t n_clips, int64_t cli
 /* ---- training step ----------------------------------------------------- */
 /* Replaces, for one batch, `output = model(data)` in train mode and `loss.backward()` of the reference's training loops
  * (wakeword_training/train_wakeword.py:109-115; WakewordTrainer.train_epoch, wakeword_training_script.py:241-267) for
- * SimpleWakewordModel: the forward with nn.LSTM's inter-layer dropout and nn.Dropout before fc (train_wakeword.py:34-35,
+ * SimpleWakewordModel and the 3-conv WakewordModel: the forward with nn.LSTM's inter-layer dropout and nn.Dropout before fc (train_wakeword.py:34-35,
  * 46-47), and d loss / d parameter given d loss / d logits.  CrossEntropyLoss and the optimiser stay with the caller.
  * Exact fp32 (f32 MFMA / VALU).  All pointers in the two structs are DEVICE pointers in torch layout (the live parameters
  * and their .grad buffers): nothing is packed on the host, the weights may change between calls.
  * Dropout factors come from a counter-based generator keyed by (seed, layer, clip, unit): the same seed reproduces the
  * step; torch's own random stream cannot be matched (documented, tests/test_gpu_train.py). */
 typedef struct ww_train_params {
-    int32_t n_conv;              /* 2 (the 3-conv model's backward is not built) */
+    int32_t n_conv;              /* 2 (SimpleWakewordModel) or 3 (WakewordModel) */
     int32_t hidden;              /* 256 */
     const float* conv_weight[3];
     const float* conv_bias[3];
@@ -256,9 +256,9 @@ typedef struct ww_train_params {
     const float* fc_bias;
 } ww_train_params;
 typedef struct ww_train_grads {  /* outputs, overwritten (not accumulated) */
-    float* conv_weight[3];       /* [32,1,3,3], [64,32,3,3] */
+    float* conv_weight[3];       /* [32,1,3,3], [64,32,3,3], [128,64,3,3] (n_conv 3) */
     float* conv_bias[3];
-    float* lstm_weight_ih[2];    /* [1024, 64], [1024, 256]; forget-gate rows come out zero like autograd's */
+    float* lstm_weight_ih[2];    /* [1024, 64 | 128], [1024, 256]; forget-gate rows come out zero like autograd's */
     float* lstm_bias[2];         /* [1024]: d/d bias_ih == d/d bias_hh; weight_hh gradients are exactly zero (h0 = 0): caller zero-fills */
     float* fc_weight;            /* [2, 256] */
     float* fc_bias;              /* [2] */
@@ -272,7 +272,7 @@ WW_API int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width,
                                  const float* dlogits_dev, void* workspace_dev, const ww_train_grads* grads, ww_stream_t stream);
 /* Diagnostic: the dropout factors (0 or 1 / (1 - p)) the last forward on this workspace applied to the layer-0 output and to
  * fc's input, [n][256] each -- lets a test replay the step in another framework with the same masks. */
-WW_API int ww_train_masks(const void* workspace_dev, int64_t n, float* mask0_dev, float* mask1_dev, ww_stream_t stream);
+WW_API int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, float* mask0_dev, float* mask1_dev, ww_stream_t stream);
 
 /* ---- streaming: sliding 1 s window, one hop per step, many microphones ------------------------ */
 /* Semantics per window = predict_wakeword (wakeword_training.ipynb cell 19): normalise the last

@@ -33,3 +33,10 @@ def golden_grads():
     """loss + parameter gradients of the reference SimpleWakewordModel (tests/golden/make_golden.py)."""
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, "grads_simple_seed1234.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_grads_full():
+    """loss + parameter gradients of the reference's own 3-conv WakewordModel class (tests/golden/make_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "grads_full_seed1234.npz")))

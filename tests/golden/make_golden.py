@@ -21,7 +21,8 @@ What is pinned
     -> model_full_seed1234.npz.
   * gradients of `SimpleWakewordModel` for the training path (wakeword_training_script.py:241-267: CrossEntropyLoss,
     loss.backward()): eval-mode forward (dropout = identity, so the numbers do not depend on torch's RNG stream),
-    loss and every parameter's .grad for x32[:4] with labels [1,0,1,0] -> grads_simple_seed1234.npz.
+    loss and every parameter's .grad for x32[:4] with labels [1,0,1,0] -> grads_simple_seed1234.npz; the same for the 3-conv
+    WakewordModel class -> grads_full_seed1234.npz.
 """
 import os
 import sys
@@ -116,6 +117,18 @@ def main():
                         weight_seed=np.int64(1234))
     print("wrote", outf, {k: v.shape for k, v in np.load(outf).items()})
     print("full logits32[:2] =", yf32[:2])
+
+    # ---- gradients of the 3-conv model's own class (training path, WakewordTrainer.train_epoch :241-267), dropout = identity ----
+    full.zero_grad()
+    lossf = torch.nn.CrossEntropyLoss()(full(torch.from_numpy(x32f)), labels)
+    lossf.backward()
+    gradsf = {k: p.grad.detach().numpy().copy() for k, p in full.named_parameters()}
+    # weight_hh gradients are exactly zero (h0 = 0): 2 x 1 MB of zeros that the test asserts instead of storing
+    assert not gradsf["lstm.weight_hh_l0"].any() and not gradsf["lstm.weight_hh_l1"].any()
+    outgf = os.path.join(HERE, "grads_full_seed1234.npz")
+    np.savez_compressed(outgf, x=x32f, labels=labels.numpy(), loss=np.float32(lossf.item()),
+                        **{"grad." + k: v for k, v in gradsf.items() if "weight_hh" not in k})
+    print("wrote", outgf, "loss", lossf.item(), {k: float(np.abs(v).max()) for k, v in gradsf.items()})
 
 
 if __name__ == "__main__":

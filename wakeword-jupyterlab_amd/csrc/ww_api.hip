@@ -307,18 +307,19 @@ static int check_train(const float* mel, int64_t n, int32_t width, const ww_trai
     if (n < 1 || n > (int64_t(1) << 24)) return fail(WW_EINVAL, "training batch %lld out of range", (long long)n);
     if (width < 1 || width > WW_MAX_WIDTH) return fail(WW_EUNSUPPORTED, "mel width %d: the conv kernels take 1..%d frames", width, WW_MAX_WIDTH);
     if (!p || !mel || !ws) return fail(WW_EINVAL, "null argument");
-    if (p->n_conv != 2 || p->hidden != kHidden) return fail(WW_EUNSUPPORTED, "the training step is built for SimpleWakewordModel (2 convs, hidden 256)");
+    if ((p->n_conv != 2 && p->n_conv != 3) || p->hidden != kHidden) return fail(WW_EUNSUPPORTED, "the training step is built for 2 or 3 convs and hidden 256");
+    for (int i = 0; i < p->n_conv; ++i)
+        if (!p->conv_weight[i] || !p->conv_bias[i]) return fail(WW_EINVAL, "null parameter pointer");
     for (int i = 0; i < 2; ++i)
-        if (!p->conv_weight[i] || !p->conv_bias[i] || !p->lstm_weight_ih[i] || !p->lstm_bias_ih[i] || !p->lstm_bias_hh[i])
-            return fail(WW_EINVAL, "null parameter pointer");
+        if (!p->lstm_weight_ih[i] || !p->lstm_bias_ih[i] || !p->lstm_bias_hh[i]) return fail(WW_EINVAL, "null parameter pointer");
     if (!p->fc_weight || !p->fc_bias) return fail(WW_EINVAL, "null parameter pointer");
     if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(WW_EINVAL, "workspace must be 256-byte aligned");
     return WW_OK;
 }
 
 int64_t ww_train_workspace_bytes(int64_t n, int32_t n_conv) {
-    if (n < 0 || n > (int64_t(1) << 24) || n_conv != 2) return fail(WW_EINVAL, "bad training workspace query");
-    return train_workspace_bytes(n);
+    if (n < 0 || n > (int64_t(1) << 24) || (n_conv != 2 && n_conv != 3)) return fail(WW_EINVAL, "bad training workspace query");
+    return train_workspace_bytes(n, n_conv);
 }
 
 int ww_train_forward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params, float p_lstm, float p_fc,
@@ -330,18 +331,20 @@ int ww_train_forward_f32(const float* mel_dev, int64_t n, int32_t width, const w
     return train_forward(mel_dev, n, width, params, p_lstm, p_fc, seed, workspace_dev, logits_dev, static_cast<hipStream_t>(stream));
 }
 
-int ww_train_masks(const void* workspace_dev, int64_t n, float* mask0_dev, float* mask1_dev, ww_stream_t stream) {
-    if (!workspace_dev || !mask0_dev || !mask1_dev || n < 1) return fail(WW_EINVAL, "bad argument");
+int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, float* mask0_dev, float* mask1_dev, ww_stream_t stream) {
+    if (!workspace_dev || !mask0_dev || !mask1_dev || n < 1 || (n_conv != 2 && n_conv != 3)) return fail(WW_EINVAL, "bad argument");
     if (int rc = require_gfx950()) return rc;
-    return train_masks(workspace_dev, n, mask0_dev, mask1_dev, static_cast<hipStream_t>(stream));
+    return train_masks(workspace_dev, n, n_conv, mask0_dev, mask1_dev, static_cast<hipStream_t>(stream));
 }
 
 int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params, const float* dlogits_dev,
                           void* workspace_dev, const ww_train_grads* grads, ww_stream_t stream) {
     if (int rc = check_train(mel_dev, n, width, params, workspace_dev)) return rc;
     if (!dlogits_dev || !grads) return fail(WW_EINVAL, "null argument");
+    for (int i = 0; i < params->n_conv; ++i)
+        if (!grads->conv_weight[i] || !grads->conv_bias[i]) return fail(WW_EINVAL, "null gradient pointer");
     for (int i = 0; i < 2; ++i)
-        if (!grads->conv_weight[i] || !grads->conv_bias[i] || !grads->lstm_weight_ih[i] || !grads->lstm_bias[i]) return fail(WW_EINVAL, "null gradient pointer");
+        if (!grads->lstm_weight_ih[i] || !grads->lstm_bias[i]) return fail(WW_EINVAL, "null gradient pointer");
     if (!grads->fc_weight || !grads->fc_bias) return fail(WW_EINVAL, "null gradient pointer");
     if (int rc = require_gfx950()) return rc;
     return train_backward(mel_dev, n, width, params, dlogits_dev, workspace_dev, grads, static_cast<hipStream_t>(stream));

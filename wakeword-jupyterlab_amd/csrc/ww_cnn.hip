@@ -1177,9 +1177,11 @@ constexpr int kC3ActFloats = 64 * kC3Rows * kRS;     // 13,056
 constexpr int kC3XchFloats = 4 * 4 * 16 * 64;        // [nt][r][j][lane] 16,384
 constexpr int kC3LdsFloats = kC3ActFloats + kC3XchFloats;
 
+// STORE (training forward): relu(conv3) is also kept, as [n][80][128][32] (row, channel, column; zero beyond `width`).
+template <bool STORE>
 __global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ in, int n, int width,
                                                       const float* __restrict__ wB, const float* __restrict__ b3,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, float* __restrict__ mid3) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* act = lds;                        // [64][6][34]
     float* xch = act + kC3ActFloats;         // [4][4][16][64]
@@ -1230,13 +1232,22 @@ __global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ 
             __syncthreads();
             if (kh == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    float vs[16];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
                         const float v = relu(acc[r][j] + xch[((nt * 4 + r) * 16 + j) * 64 + lane] + bias);
-                        pool += (col < width) ? v : 0.f;
+                        vs[j] = (col < width) ? v : 0.f;
+                        pool += vs[j];
                     }
+                    if constexpr (STORE) {
+                        float* dst = mid3 + ((int64_t(clip) * kH + y0 + r) * 128 + 32 * nt + x) * kW + 4 * h;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(vs[4 * g], vs[4 * g + 1], vs[4 * g + 2], vs[4 * g + 3]);
+                    }
+                }
             }
         }
         if (kh == 0) {
@@ -1390,7 +1401,9 @@ static int opt_in_lds() {
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
-    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(sizeof(float) * kC3LdsFloats)));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                int(sizeof(float) * kC3LdsFloats)));
     done[dev] = true;
     return WW_OK;
@@ -1403,6 +1416,18 @@ int launch_cnn2_f32_mid(const float* mel, int64_t n, int width, const float* w1,
     const int64_t cus = device_cu_count();
     const int grid2 = int(n < 2 * cus ? n : 2 * cus);
     hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid2), dim3(256), sizeof(float) * kC2LdsFloats, stream, mel, int(n), width, w1, b1, wB, b2, mid);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// training forward of the 3-conv model: conv3 + ReLU + pool in exact fp32 from relu(conv2) [n][80][64][32], keeping relu(conv3)
+int launch_cnn3_f32_store(const float* mid2, int64_t n, int width, const float* wB, const float* b3, float* pooled, float* mid3,
+                          hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    if (int rc = opt_in_lds()) return rc;
+    const int64_t cus = device_cu_count();
+    hipLaunchKernelGGL(cnn3_kernel<true>, dim3(int(n < cus ? n : cus)), dim3(512), sizeof(float) * kC3LdsFloats, stream, mid2, int(n), width, wB, b3,
+                       pooled, mid3);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
@@ -1469,8 +1494,8 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
     hipLaunchKernelGGL(cnn2_kernel<false>, dim3(grid2), dim3(256), lds2, stream, mel, int(n), width,
                        packed + L.conv1_w, packed + L.conv1_b, packed + L.conv2_w, packed + L.conv2_b, mid);
     WW_HIP(hipGetLastError());
-    hipLaunchKernelGGL(cnn3_kernel, dim3(grid1), dim3(512), sizeof(float) * kC3LdsFloats, stream, mid, int(n), width,
-                       packed + L.conv3_w, packed + L.conv3_b, pooled);
+    hipLaunchKernelGGL(cnn3_kernel<false>, dim3(grid1), dim3(512), sizeof(float) * kC3LdsFloats, stream, mid, int(n), width,
+                       packed + L.conv3_w, packed + L.conv3_b, pooled, static_cast<float*>(nullptr));
     WW_HIP(hipGetLastError());
     return WW_OK;
 }

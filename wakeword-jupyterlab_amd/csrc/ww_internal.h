@@ -131,10 +131,10 @@ int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_co
                    float* prob /*nullable*/, hipStream_t stream);
 
 // training step (ww_train.hip)
-int64_t train_workspace_bytes(int64_t n);
+int64_t train_workspace_bytes(int64_t n, int n_conv);
 int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
                   float* logits, hipStream_t st);
-int train_masks(const void* workspace, int64_t n, float* mask0, float* mask1, hipStream_t st);
+int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, float* mask1, hipStream_t st);
 int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
                    const ww_train_grads* g, hipStream_t st);
 

@@ -18,6 +18,8 @@
 // The LSTM step with zero state has the closed form of ww_head.hip; its backward is elementwise (lstm_gates_bwd_kernel) plus
 // six small GEMMs (sgemm_kernel).  W_hh gradients are exactly zero (h0 = 0) and are left to the caller to zero-fill.
 // Every reduction over clips runs in a fixed order (per-workgroup partials + reduce_partials_kernel): bitwise repeatable.
+#include <mutex>
+
 #include "ww_internal.h"
 
 namespace ww {
@@ -41,13 +43,15 @@ __global__ void pack_conv_b_dev_kernel(const float* __restrict__ w, int cout, in
         out[i] = w[((co * cin + ci) * 3 + dy) * 3 + dx];
     }
 }
-// conv2 weight [64][32][3][3] -> B operand of the data-gradient kernel (a correlation of gm with the FLIPPED, transposed
-// weights): out[(kh*144 + (c*3+dy)*3+dx)*64 + lane] = W[32 kh + 2c + (lane>>5)][lane&31][2-dy][2-dx]
-__global__ void pack_dgrad_b_dev_kernel(const float* __restrict__ w, float* __restrict__ out) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 144 * 64; i += gridDim.x * blockDim.x) {
-        const int lane = i & 63, r = i >> 6, kh = r / 144, s = r - kh * 144, c = s / 9, dy = (s % 9) / 3, dx = s % 3;
-        const int co = 32 * kh + 2 * c + (lane >> 5), ci = lane & 31;
-        out[i] = w[((co * 32 + ci) * 3 + (2 - dy)) * 3 + (2 - dx)];
+// conv weight [COUT][CIN][3][3] -> B operands of the data-gradient kernel (a correlation of gm with the FLIPPED, transposed weights):
+// out[((nt*KQ + kq)*144 + (c*3+dy)*3+dx)*64 + lane] = W[32 kq + 2c + (lane>>5)][32 nt + (lane&31)][2-dy][2-dx],  KQ = COUT/32
+__global__ void pack_dgrad_b_dev_kernel(const float* __restrict__ w, int cout, int cin, float* __restrict__ out) {
+    const int kqn = cout / 32, total = (cin / 32) * kqn * 144 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63, r = i >> 6, blk = r / 144, s = r - blk * 144, nt = blk / kqn, kq = blk - nt * kqn;
+        const int c = s / 9, dy = (s % 9) / 3, dx = s % 3;
+        const int co = 32 * kq + 2 * c + (lane >> 5), ci = 32 * nt + (lane & 31);
+        out[i] = w[((co * cin + ci) * 3 + (2 - dy)) * 3 + (2 - dx)];
     }
 }
 
@@ -79,30 +83,45 @@ __device__ __forceinline__ void load_mel_tile(const float* __restrict__ src, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv2 weight gradient.  512 threads = 8 waves: wave = (co half ch, row pair rp); 8-row bands.
-//   dW2[co][ci][tap] += sum over the band's positions gm[co][y][x] * a1[ci][y+dy-1][x+dx-1]
-// as v_mfma_f32_32x32x2_f32 with M = co (32 of the half), N = ci, K = two neighbouring columns; the nine taps' 32x32
-// accumulators (144 VGPRs) stay in registers over ALL clips of the persistent workgroup.  LDS: log-mel tile, a1 band
-// [32 ci][10 rows][34] (ci stride 341: conflict-free across ci), gm band [8 rows][64 co][33].
-// Output: one partial [64][32][9] + [64] (bias) per workgroup -> reduce_partials_kernel.
+// Weight gradient of a 3x3 convolution CIN -> COUT.  512 threads = 8 waves: wave = (block of 32 co x 32 ci, row split).
+//   dW[co][ci][tap] += sum over the band's positions gm[co][y][x] * a[ci][y+dy-1][x+dx-1]
+// as v_mfma_f32_32x32x2_f32 with M = co, N = ci, K = two neighbouring columns; a wave's nine 32x32 accumulators (144 VGPRs) stay in
+// registers over ALL clips of the persistent workgroup.
+//   gm   !DENSE: gp[b][co] * [oact > 0] (the conv feeds the global average pool: rank-one gradient);  DENSE: the tensor dz itself
+//   a    FROM_MEL: relu(conv1) recomputed from the log-mel tile (CIN = 32);  else loaded from the stored activations iact
+// All activation / gradient tensors are [b][row][channel][32 columns] floats (cnn2_kernel<false>'s layout).
+// conv2: <32, 64, 8>: 2 blocks x 4 row pairs.  conv3: <64, 128, 4>: 8 blocks, each wave all 4 rows of the band.
+// Output: one partial [COUT][CIN][9] + [COUT] (bias) per workgroup -> reduce_partials_kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int kWgActCi = 10 * kTRS + 1;                     // 341
-constexpr int kWgActFloats = 32 * kWgActCi;                 // 10,912
-constexpr int kWgGmFloats = 8 * 64 * 33;                    // 16,896
-constexpr int kWgLdsFloats = kTMelFloats + kWgActFloats + kWgGmFloats;
-constexpr int kWgPartial = 64 * 32 * 9 + 64;                // floats per workgroup
+template <int CIN, int COUT, int BAND>
+struct WgradCfg {
+    static constexpr int kBlocks = (COUT / 32) * (CIN / 32);
+    static constexpr int kSplits = 8 / kBlocks;                   // row splits of a band over waves
+    static constexpr int kRowsPerWave = BAND / kSplits;
+    static constexpr int kActCi = (BAND + 2) * kTRS + 1;          // odd stride: conflict-free across ci
+    static constexpr int kActFloats = CIN * kActCi;
+    static constexpr int kGmFloats = BAND * COUT * 33;
+    static constexpr int kLdsFloats = kTMelFloats + kActFloats + kGmFloats;
+    static constexpr int kPartial = COUT * CIN * 9 + COUT;
+    static_assert(kBlocks == 2 || kBlocks == 8, "eight waves: 2 blocks x 4 row splits, or 8 blocks");
+    static_assert(BAND % kSplits == 0 && kLdsFloats * 4 <= 160 * 1024, "band does not fit");
+};
 
-__global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(const float* __restrict__ mel, const float* __restrict__ mid,
-                                                             const float* __restrict__ gp /*[n][64]*/, int n, int width,
-                                                             const float* __restrict__ w1, const float* __restrict__ b1,
-                                                             float* __restrict__ partial /*[grid][kWgPartial]*/) {
+template <int CIN, int COUT, int BAND, bool DENSE, bool FROM_MEL>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const float* __restrict__ mel, const float* __restrict__ iact,
+                                                            const float* __restrict__ oact_or_dz, const float* __restrict__ gp /*[n][COUT]*/,
+                                                            int n, int width, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            float* __restrict__ partial) {
+    using Cfg = WgradCfg<CIN, COUT, BAND>;
+    static_assert(!FROM_MEL || CIN == 32, "conv1 feeds a 32-channel input");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* melt = lds;
     float* act = melt + kTMelFloats;
-    float* gm = act + kWgActFloats;
+    float* gm = act + Cfg::kActFloats;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ch = wave & 1, rp = wave >> 1;
+    const int blk = wave % Cfg::kBlocks, rp = wave / Cfg::kBlocks;
+    const int cob = blk % (COUT / 32), cib = blk / (COUT / 32);
     const int m = lane & 31, kk = lane >> 5;
 
     f32x16 acc[9];
@@ -110,59 +129,84 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(const float* __rest
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
-    float db2 = 0.f;                                        // loader role: fixed co = tid >> 3 for every row
-    for (int i = tid; i < kWgLdsFloats; i += 512) lds[i] = 0.f;
+    constexpr int kGmPasses = COUT / 64;                          // a row of gm = COUT x 32 floats = kGmPasses x (512 threads x float4)
+    float db[kGmPasses];
+#pragma unroll
+    for (int p = 0; p < kGmPasses; ++p) db[p] = 0.f;
+    for (int i = tid; i < Cfg::kLdsFloats; i += 512) lds[i] = 0.f;
 
-    const int lco = tid >> 3, lcol = (tid & 7) * 4;
-    const int cx = tid & 31, cg = tid >> 5;                 // conv1 role: column, channels 2 cg, 2 cg + 1
+    const int lrow8 = tid >> 3, lcol = (tid & 7) * 4;              // loader role: channel (tid >> 3) + 64 * pass, four columns
+    const int cx = tid & 31, cg = tid >> 5;                        // conv1 role: column, channels 2 cg, 2 cg + 1
     float w1r[2][9], b1r[2];
+    if constexpr (FROM_MEL) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w1r[u][t] = w1[(2 * cg + u) * 9 + t];
-        b1r[u] = b1[2 * cg + u];
+            for (int t = 0; t < 9; ++t) w1r[u][t] = w1[(2 * cg + u) * 9 + t];
+            b1r[u] = b1[2 * cg + u];
+        }
     }
 
     for (int clip = blockIdx.x; clip < n; clip += gridDim.x) {
         __syncthreads();
-        load_mel_tile(mel + int64_t(clip) * kTH * width, width, melt, tid, 512);
-        const float g = gp[int64_t(clip) * 64 + lco];
-        for (int band = 0; band < kTH / 8; ++band) {
-            const int y0 = band * 8;
+        if constexpr (FROM_MEL) load_mel_tile(mel + int64_t(clip) * kTH * width, width, melt, tid, 512);
+        float g[kGmPasses];
+#pragma unroll
+        for (int p = 0; p < kGmPasses; ++p) g[p] = DENSE ? 0.f : gp[int64_t(clip) * COUT + lrow8 + 64 * p];
+        for (int band = 0; band < kTH / BAND; ++band) {
+            const int y0 = band * BAND;
             __syncthreads();          // mel tile ready / the previous band's operand reads retired
-            // gm band: gp * [relu(conv2) > 0]
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float4 v = *reinterpret_cast<const float4*>(mid + ((int64_t(clip) * kTH + y0 + r) * 64 + lco) * kTW + lcol);
-                float* d = gm + (r * 64 + lco) * 33 + lcol;
-                const float g0 = v.x > 0.f ? g : 0.f, g1 = v.y > 0.f ? g : 0.f, g2 = v.z > 0.f ? g : 0.f, g3 = v.w > 0.f ? g : 0.f;
-                d[0] = g0; d[1] = g1; d[2] = g2; d[3] = g3;
-                db2 += (g0 + g1) + (g2 + g3);
-            }
-            // a1 band: rows y0-1 .. y0+8, zero outside the image and beyond `width`
+            for (int r = 0; r < BAND; ++r)
+#pragma unroll
+                for (int p = 0; p < kGmPasses; ++p) {
+                    const int co = lrow8 + 64 * p;
+                    const float4 v = *reinterpret_cast<const float4*>(oact_or_dz + ((int64_t(clip) * kTH + y0 + r) * COUT + co) * kTW + lcol);
+                    float* d = gm + (r * COUT + co) * 33 + lcol;
+                    float g0, g1, g2, g3;
+                    if constexpr (DENSE) { g0 = v.x; g1 = v.y; g2 = v.z; g3 = v.w; }
+                    else { g0 = v.x > 0.f ? g[p] : 0.f; g1 = v.y > 0.f ? g[p] : 0.f; g2 = v.z > 0.f ? g[p] : 0.f; g3 = v.w > 0.f ? g[p] : 0.f; }
+                    d[0] = g0; d[1] = g1; d[2] = g2; d[3] = g3;
+                    db[p] += (g0 + g1) + (g2 + g3);
+                }
+            // input activations of the band: rows y0-1 .. y0+BAND, zero outside the image and beyond `width`
+            if constexpr (FROM_MEL) {
 #pragma unroll 1
-            for (int q = 0; q < 10; ++q) {
-                const int y = y0 - 1 + q;
-                const bool inside = y >= 0 && y < kTH && cx < width;
-                const float* mp = melt + (inside ? y : 0) * kTMelRS + cx;
-                const float m00 = mp[0], m01 = mp[1], m02 = mp[2], m10 = mp[kTMelRS], m11 = mp[kTMelRS + 1], m12 = mp[kTMelRS + 2],
-                            m20 = mp[2 * kTMelRS], m21 = mp[2 * kTMelRS + 1], m22 = mp[2 * kTMelRS + 2];
+                for (int q = 0; q < BAND + 2; ++q) {
+                    const int y = y0 - 1 + q;
+                    const bool inside = y >= 0 && y < kTH && cx < width;
+                    const float* mp = melt + (inside ? y : 0) * kTMelRS + cx;
+                    const float m00 = mp[0], m01 = mp[1], m02 = mp[2], m10 = mp[kTMelRS], m11 = mp[kTMelRS + 1], m12 = mp[kTMelRS + 2],
+                                m20 = mp[2 * kTMelRS], m21 = mp[2 * kTMelRS + 1], m22 = mp[2 * kTMelRS + 2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    float v = b1r[u];
-                    v = fmaf(w1r[u][0], m00, v); v = fmaf(w1r[u][1], m01, v); v = fmaf(w1r[u][2], m02, v);
-                    v = fmaf(w1r[u][3], m10, v); v = fmaf(w1r[u][4], m11, v); v = fmaf(w1r[u][5], m12, v);
-                    v = fmaf(w1r[u][6], m20, v); v = fmaf(w1r[u][7], m21, v); v = fmaf(w1r[u][8], m22, v);
-                    act[(2 * cg + u) * kWgActCi + q * kTRS + cx + 1] = inside ? relu_t(v) : 0.f;
+                    for (int u = 0; u < 2; ++u) {
+                        float v = b1r[u];
+                        v = fmaf(w1r[u][0], m00, v); v = fmaf(w1r[u][1], m01, v); v = fmaf(w1r[u][2], m02, v);
+                        v = fmaf(w1r[u][3], m10, v); v = fmaf(w1r[u][4], m11, v); v = fmaf(w1r[u][5], m12, v);
+                        v = fmaf(w1r[u][6], m20, v); v = fmaf(w1r[u][7], m21, v); v = fmaf(w1r[u][8], m22, v);
+                        act[(2 * cg + u) * Cfg::kActCi + q * kTRS + cx + 1] = inside ? relu_t(v) : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int q = 0; q < BAND + 2; ++q) {
+                    const int y = y0 - 1 + q;
+#pragma unroll
+                    for (int p = 0; p < CIN / 64; ++p) {
+                        const int ci = lrow8 + 64 * p;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (y >= 0 && y < kTH) v = *reinterpret_cast<const float4*>(iact + ((int64_t(clip) * kTH + y) * CIN + ci) * kTW + lcol);
+                        float* d = act + ci * Cfg::kActCi + q * kTRS + lcol + 1;
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    }
                 }
             }
             __syncthreads();
-            // this wave: output rows 2 rp, 2 rp + 1 of the band, co half ch
 #pragma unroll 1
-            for (int rr = 0; rr < 2; ++rr) {
-                const int qo = 2 * rp + rr;
-                const float* ga = gm + (qo * 64 + 32 * ch + m) * 33 + kk;
-                const float* ba = act + m * kWgActCi + qo * kTRS + kk;
+            for (int rr = 0; rr < Cfg::kRowsPerWave; ++rr) {
+                const int qo = rp * Cfg::kRowsPerWave + rr;
+                const float* ga = gm + (qo * COUT + 32 * cob + m) * 33 + kk;
+                const float* ba = act + (32 * cib + m) * Cfg::kActCi + qo * kTRS + kk;
 #pragma unroll 2
                 for (int x0 = 0; x0 < kTW; x0 += 2) {
                     const float a = ga[x0];
@@ -175,97 +219,116 @@ __global__ __launch_bounds__(512, 2) void conv2_wgrad_kernel(const float* __rest
             }
         }
     }
-    // sum the four row pairs through LDS in fixed order, write this workgroup's partial
+    // sum the row splits through LDS in fixed order, tap by tap; write this workgroup's partial
     __syncthreads();
-    float* xch = lds;                                        // [rp][ch][tap][16][64] = 73,728 floats > the tiles: go tap by tap
-    float* outp = partial + int64_t(blockIdx.x) * kWgPartial;
+    float* xch = lds;                                        // [8 waves][16][64] = 8,192 floats per tap
+    float* outp = partial + int64_t(blockIdx.x) * Cfg::kPartial;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {             // unrolled: a runtime index would put the accumulators in scratch memory
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xch[((rp * 2 + ch) * 16 + j) * 64 + lane] = acc[t][j];
+        for (int j = 0; j < 16; ++j) xch[(wave * 16 + j) * 64 + lane] = acc[t][j];
         __syncthreads();
         if (rp == 0) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                float s = 0.f;
+                float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s += xch[((r * 2 + ch) * 16 + j) * 64 + lane];
-                const int co = 32 * ch + (j & 3) + 8 * (j >> 2) + 4 * kk, ci = m;      // D: lane&31 = n, register j <-> row m
-                outp[(co * 32 + ci) * 9 + t] = s;
+                for (int r = 0; r < Cfg::kSplits; ++r) sum += xch[((r * Cfg::kBlocks + blk) * 16 + j) * 64 + lane];
+                const int co = 32 * cob + (j & 3) + 8 * (j >> 2) + 4 * kk, ci = 32 * cib + m;      // D: lane&31 = n, register j <-> row m
+                outp[(co * CIN + ci) * 9 + t] = sum;
             }
         }
         __syncthreads();
     }
-    db2 += __shfl_xor(db2, 1);
-    db2 += __shfl_xor(db2, 2);
-    db2 += __shfl_xor(db2, 4);
-    if ((tid & 7) == 0) outp[64 * 32 * 9 + lco] = db2;
+#pragma unroll
+    for (int p = 0; p < kGmPasses; ++p) {
+        float d = db[p];
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 4);
+        if ((tid & 7) == 0) outp[COUT * CIN * 9 + lrow8 + 64 * p] = d;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv2 data gradient + conv1 gradients.  256 threads = 4 waves: wave = (K half kh: 32 of the 64 co, row group rg of 4 rows);
-// 8-row bands; da1 = correlation of gm (64 channels) with the flipped weights, M = 32 columns, N = ci, K = (co, tap):
-// the forward kernels' mfma_rows4 structure with 144 resident B-operand VGPRs per wave, the two K halves summed through LDS.
-// Epilogue per da1 value: the sign of conv1 recomputed from the log-mel tile (broadcast LDS reads), dW1 / db1 accumulated in
-// registers over all clips.  LDS: log-mel tile, gm band with halo [64 co][10 rows][34], exchange [2 rg][4][16][64].
+// Data gradient of a 3x3 convolution CIN -> COUT (gradient wrt its CIN-channel input) = correlation of gm (COUT channels) with the
+// flipped, transposed weights: the forward kernels' mfma_rows4 structure, M = 32 columns, N = 32 of the CIN channels, K = (co, tap) in
+// chunks of 144 k-steps = 32 co.  Waves = (K chunk kq of COUT/32, N tile nt of CIN/32, row group rg of 4 rows), 144 resident B-operand
+// VGPRs each; the K chunks are summed through LDS in a fixed chain kq = last -> ... -> 0.
+//   conv2: <32, 64>: 2 chunks x 1 tile x 2 row groups = 4 waves, 8-row bands.   conv3: <64, 128>: 4 x 2 x 1 = 8 waves, 4-row bands.
+//   TO_CONV1: epilogue = conv1's sign recomputed from the log-mel tile, dW1 / db1 accumulated (float64) over all clips -> partial [32*9 + 32]
+//   else:     epilogue = dz_out[b][row][ci][col] = da * [iact > 0]   (the dense gradient the next-lower layer's kernels take)
 // ------------------------------------------------------------------------------------------------
-constexpr int kDgGmFloats = 64 * 10 * kTRS;                 // 21,760
-constexpr int kDgXchFloats = 2 * 4 * 16 * 64;               // 8,192
-constexpr int kDgLdsFloats = kTMelFloats + kDgGmFloats + kDgXchFloats;
+template <int CIN, int COUT>
+struct DgradCfg {
+    static constexpr int kKq = COUT / 32, kNt = CIN / 32;
+    static constexpr int kRg = 8 / (kKq * kNt) >= 2 ? 2 : 1;       // conv2: 2 row groups (4 waves), conv3: 1 (8 waves)
+    static constexpr int kWaves = kKq * kNt * kRg;
+    static constexpr int kBand = 4 * kRg;
+    static constexpr int kGmFloats = COUT * (kBand + 2) * kTRS;
+    static constexpr int kXchFloats = kRg * kNt * 4 * 16 * 64;
+    static constexpr int kLdsFloats = kTMelFloats + kGmFloats + kXchFloats;
+    static_assert(kLdsFloats * 4 <= 160 * 1024, "band does not fit");
+};
 constexpr int kDgPartial = 32 * 9 + 32;
 
-__global__ __launch_bounds__(256, 1) void conv2_dgrad_kernel(const float* __restrict__ mel, const float* __restrict__ mid,
-                                                             const float* __restrict__ gp, int n, int width,
-                                                             const float* __restrict__ w1, const float* __restrict__ b1,
-                                                             const float* __restrict__ wB /*pack_dgrad_b_dev_kernel*/,
-                                                             float* __restrict__ partial /*[grid][kDgPartial]*/) {
+template <int CIN, int COUT, bool DENSE, bool TO_CONV1>
+__global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dgrad_kernel(
+    const float* __restrict__ mel, const float* __restrict__ iact, const float* __restrict__ oact_or_dz, const float* __restrict__ gp, int n,
+    int width, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wB, float* __restrict__ out) {
+    using Cfg = DgradCfg<CIN, COUT>;
+    constexpr int T = Cfg::kWaves * 64, R = Cfg::kBand + 2;
+    static_assert(T / 4 == COUT, "loader: COUT channels x 4 threads x 8 columns");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* melt = lds;
-    float* gmt = melt + kTMelFloats;                        // [64][10][34]
-    float* xch = gmt + kDgGmFloats;
+    float* gmt = melt + kTMelFloats;                        // [COUT][R][34]
+    float* xch = gmt + Cfg::kGmFloats;                      // [rg][nt][4][16][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wave & 1, rg = wave >> 1;
-    const int ci = lane & 31, h = lane >> 5;
+    const int kq = wave % Cfg::kKq, nt = (wave / Cfg::kKq) % Cfg::kNt, rg = wave / (Cfg::kKq * Cfg::kNt);
+    const int ln = lane & 31, h = lane >> 5;                // D: lane & 31 = input channel within the tile; A: lane & 31 = column
 
     float wb[144];
 #pragma unroll
-    for (int i = 0; i < 144; ++i) wb[i] = wB[(kh * 144 + i) * 64 + lane];
-    float w1r[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) w1r[t] = w1[ci * 9 + t];
-    const float b1r = b1[ci];
-    // float64 accumulators: a conv1 weight gradient is a sum of ~10^5 products dz * mel per workgroup with heavy cancellation
-    // (mel ~ -35 +- 15 dB against a dz that sums to almost nothing); in float32 the order of summation alone moves it by 1e-4
+    for (int i = 0; i < 144; ++i) wb[i] = wB[((nt * Cfg::kKq + kq) * 144 + i) * 64 + lane];
+    float w1r[9], b1r = 0.f;
     double dw1[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, db1 = 0.;
-    for (int i = tid; i < kDgLdsFloats; i += 256) lds[i] = 0.f;
+    if constexpr (TO_CONV1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w1r[t] = w1[ln * 9 + t];
+        b1r = b1[ln];
+    }
+    for (int i = tid; i < Cfg::kLdsFloats; i += T) lds[i] = 0.f;
 
-    const int lco = tid >> 2, lcol = (tid & 3) * 8;          // loader role: 64 co x 4 threads x 8 columns
-    const float* ap = gmt + ((32 * kh + h) * 10 + rg * 4) * kTRS + ci;     // A operand: lane&31 = column here (see below)
+    const int lco = tid >> 2, lcol = (tid & 3) * 8;          // loader role: COUT channels x 4 threads x 8 columns
+    const float* ap = gmt + ((32 * kq + h) * R + rg * 4) * kTRS + ln;
+    float* xw = xch + ((rg * Cfg::kNt + nt) * 4) * 16 * 64 + lane;
 
     for (int clip = blockIdx.x; clip < n; clip += gridDim.x) {
         __syncthreads();
-        load_mel_tile(mel + int64_t(clip) * kTH * width, width, melt, tid, 256);
-        const float g = gp[int64_t(clip) * 64 + lco];
-        for (int band = 0; band < kTH / 8; ++band) {
-            const int y0 = band * 8;
+        if constexpr (TO_CONV1) load_mel_tile(mel + int64_t(clip) * kTH * width, width, melt, tid, T);
+        const float g = DENSE ? 0.f : gp[int64_t(clip) * COUT + lco];
+        for (int band = 0; band < kTH / Cfg::kBand; ++band) {
+            const int y0 = band * Cfg::kBand;
             __syncthreads();
-            // gm band with halo: rows y0-1 .. y0+8, zero outside the image
 #pragma unroll 1
-            for (int q = 0; q < 10; ++q) {
+            for (int q = 0; q < R; ++q) {                     // gm band with halo: rows y0-1 .. y0+kBand, zero outside the image
                 const int y = y0 - 1 + q;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
                 if (y >= 0 && y < kTH) {
-                    const float* src = mid + ((int64_t(clip) * kTH + y) * 64 + lco) * kTW + lcol;
+                    const float* src = oact_or_dz + ((int64_t(clip) * kTH + y) * COUT + lco) * kTW + lcol;
                     a = *reinterpret_cast<const float4*>(src);
                     b = *reinterpret_cast<const float4*>(src + 4);
                 }
-                float* d = gmt + (lco * 10 + q) * kTRS + lcol + 1;
-                d[0] = a.x > 0.f ? g : 0.f; d[1] = a.y > 0.f ? g : 0.f; d[2] = a.z > 0.f ? g : 0.f; d[3] = a.w > 0.f ? g : 0.f;
-                d[4] = b.x > 0.f ? g : 0.f; d[5] = b.y > 0.f ? g : 0.f; d[6] = b.z > 0.f ? g : 0.f; d[7] = b.w > 0.f ? g : 0.f;
+                float* d = gmt + (lco * R + q) * kTRS + lcol + 1;
+                if constexpr (DENSE) {
+                    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+                } else {
+                    d[0] = a.x > 0.f ? g : 0.f; d[1] = a.y > 0.f ? g : 0.f; d[2] = a.z > 0.f ? g : 0.f; d[3] = a.w > 0.f ? g : 0.f;
+                    d[4] = b.x > 0.f ? g : 0.f; d[5] = b.y > 0.f ? g : 0.f; d[6] = b.z > 0.f ? g : 0.f; d[7] = b.w > 0.f ? g : 0.f;
+                }
             }
             __syncthreads();
-            // 144 k-steps (16 co pairs of this half x 3 x 3) over this wave's 4 rows.  A[m = column][k = co parity], B = wb.
             f32x16 acc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -277,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void conv2_dgrad_kernel(const float* __rest
                 for (int dx = 0; dx < 3; ++dx) {
                     float a[6];
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) a[q] = ap[(2 * c * 10 + q) * kTRS + dx];
+                    for (int q = 0; q < 6; ++q) a[q] = ap[(2 * c * R + q) * kTRS + dx];
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -285,55 +348,84 @@ __global__ __launch_bounds__(256, 1) void conv2_dgrad_kernel(const float* __rest
                             acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r + dy], wb[(c * 3 + dy) * 3 + dx], acc[r], 0, 0, 0);
                 }
             }
-            if (kh == 1) {
+            // K chunks summed in the fixed chain kq = last -> ... -> 0 through one exchange slot per (rg, nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+            for (int st = Cfg::kKq - 1; st >= 1; --st) {
+                if (kq == st) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) xch[((rg * 4 + r) * 16 + j) * 64 + lane] = acc[r][j];
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) xw[(r * 16 + j) * 64] = acc[r][j];
+                }
+                __syncthreads();
+                if (kq == st - 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc[r][j] += xw[(r * 16 + j) * 64];
+                }
+                if (st > 1) __syncthreads();
             }
-            __syncthreads();
-            if (kh == 0) {
-                // D: lane&31 = n = ci, register j <-> column (j&3) + 8 (j>>2) + 4 h
+            if (kq == 0) {
+                // D: lane&31 = input channel 32 nt + ln, register j <-> column (j&3) + 8 (j>>2) + 4 h
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int y = y0 + rg * 4 + r;
+                    if constexpr (TO_CONV1) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
-                        const float da = acc[r][j] + xch[((rg * 4 + r) * 16 + j) * 64 + lane];
-                        const float* mp = melt + y * kTMelRS + col;          // taps: tile rows y..y+2, columns col..col+2
-                        const float m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[kTMelRS], m4 = mp[kTMelRS + 1], m5 = mp[kTMelRS + 2],
-                                    m6 = mp[2 * kTMelRS], m7 = mp[2 * kTMelRS + 1], m8 = mp[2 * kTMelRS + 2];
-                        float z = b1r;
-                        z = fmaf(w1r[0], m0, z); z = fmaf(w1r[1], m1, z); z = fmaf(w1r[2], m2, z);
-                        z = fmaf(w1r[3], m3, z); z = fmaf(w1r[4], m4, z); z = fmaf(w1r[5], m5, z);
-                        z = fmaf(w1r[6], m6, z); z = fmaf(w1r[7], m7, z); z = fmaf(w1r[8], m8, z);
-                        const double dz = (z > 0.f && col < width) ? double(da) : 0.0;
-                        dw1[0] = fma(dz, double(m0), dw1[0]); dw1[1] = fma(dz, double(m1), dw1[1]); dw1[2] = fma(dz, double(m2), dw1[2]);
-                        dw1[3] = fma(dz, double(m3), dw1[3]); dw1[4] = fma(dz, double(m4), dw1[4]); dw1[5] = fma(dz, double(m5), dw1[5]);
-                        dw1[6] = fma(dz, double(m6), dw1[6]); dw1[7] = fma(dz, double(m7), dw1[7]); dw1[8] = fma(dz, double(m8), dw1[8]);
-                        db1 += dz;
+                        for (int j = 0; j < 16; ++j) {
+                            const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
+                            const float da = acc[r][j];
+                            const float* mp = melt + y * kTMelRS + col;          // taps: tile rows y..y+2, columns col..col+2
+                            const float m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[kTMelRS], m4 = mp[kTMelRS + 1], m5 = mp[kTMelRS + 2],
+                                        m6 = mp[2 * kTMelRS], m7 = mp[2 * kTMelRS + 1], m8 = mp[2 * kTMelRS + 2];
+                            float z = b1r;
+                            z = fmaf(w1r[0], m0, z); z = fmaf(w1r[1], m1, z); z = fmaf(w1r[2], m2, z);
+                            z = fmaf(w1r[3], m3, z); z = fmaf(w1r[4], m4, z); z = fmaf(w1r[5], m5, z);
+                            z = fmaf(w1r[6], m6, z); z = fmaf(w1r[7], m7, z); z = fmaf(w1r[8], m8, z);
+                            const double dz = (z > 0.f && col < width) ? double(da) : 0.0;
+                            dw1[0] = fma(dz, double(m0), dw1[0]); dw1[1] = fma(dz, double(m1), dw1[1]); dw1[2] = fma(dz, double(m2), dw1[2]);
+                            dw1[3] = fma(dz, double(m3), dw1[3]); dw1[4] = fma(dz, double(m4), dw1[4]); dw1[5] = fma(dz, double(m5), dw1[5]);
+                            dw1[6] = fma(dz, double(m6), dw1[6]); dw1[7] = fma(dz, double(m7), dw1[7]); dw1[8] = fma(dz, double(m8), dw1[8]);
+                            db1 += dz;
+                        }
+                    } else {
+                        const int64_t at = ((int64_t(clip) * kTH + y) * CIN + 32 * nt + ln) * kTW + 4 * h;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const float4 ia = *reinterpret_cast<const float4*>(iact + at + 8 * gq);
+                            float4 dz;
+                            dz.x = ia.x > 0.f ? acc[r][4 * gq + 0] : 0.f;
+                            dz.y = ia.y > 0.f ? acc[r][4 * gq + 1] : 0.f;
+                            dz.z = ia.z > 0.f ? acc[r][4 * gq + 2] : 0.f;
+                            dz.w = ia.w > 0.f ? acc[r][4 * gq + 3] : 0.f;
+                            *reinterpret_cast<float4*>(out + at + 8 * gq) = dz;
+                        }
                     }
                 }
             }
         }
     }
-    // the two column halves (lane ^ 32) and the two row groups, in fixed order -> this workgroup's partial
-    __syncthreads();
-    double* red = reinterpret_cast<double*>(xch);            // [rg][h][10][32] doubles = 10 KB of the 32 KB exchange area
-    if (kh == 0) {
+    if constexpr (TO_CONV1) {
+        // the two column halves (h) and the row groups, in fixed order -> this workgroup's partial
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(xch);            // [rg][h][10][32] doubles
+        if (kq == 0) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) red[((rg * 2 + h) * 10 + t) * 32 + ci] = dw1[t];
-        red[((rg * 2 + h) * 10 + 9) * 32 + ci] = db1;
-    }
-    __syncthreads();
-    float* outp = partial + int64_t(blockIdx.x) * kDgPartial;
-    if (tid < 32) {
+            for (int t = 0; t < 9; ++t) red[((rg * 2 + h) * 10 + t) * 32 + ln] = dw1[t];
+            red[((rg * 2 + h) * 10 + 9) * 32 + ln] = db1;
+        }
+        __syncthreads();
+        float* outp = out + int64_t(blockIdx.x) * kDgPartial;
+        if (tid < 32) {
 #pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            const double s = (red[(0 * 10 + t) * 32 + tid] + red[(1 * 10 + t) * 32 + tid]) + (red[(2 * 10 + t) * 32 + tid] + red[(3 * 10 + t) * 32 + tid]);
-            if (t < 9) outp[tid * 9 + t] = float(s);
-            else outp[32 * 9 + tid] = float(s);
+            for (int t = 0; t < 10; ++t) {
+                double sum = 0.0;
+#pragma unroll
+                for (int i = 0; i < 2 * Cfg::kRg; ++i) sum += red[(i * 10 + t) * 32 + tid];
+                if (t < 9) outp[tid * 9 + t] = float(sum);
+                else outp[32 * 9 + tid] = float(sum);
+            }
         }
     }
 }
@@ -441,65 +533,77 @@ __global__ void scale_kernel(const float* __restrict__ x, float s, int64_t len, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// workspace
+// workspace and orchestration
 // ------------------------------------------------------------------------------------------------
 int launch_cnn2_f32_mid(const float* mel, int64_t n, int width, const float* w1, const float* b1, const float* wB, const float* b2, float* mid,
                         hipStream_t stream);   // ww_cnn.hip
+int launch_cnn3_f32_store(const float* mid2, int64_t n, int width, const float* wB, const float* b3, float* pooled, float* mid3,
+                          hipStream_t stream);   // ww_cnn.hip
 int launch_lstm_fc_train(const float* pooled, int64_t n, int C, const float* w_ih0, const float* b_ih0, const float* b_hh0,
                          const float* w_ih1, const float* b_ih1, const float* b_hh1, const float* fcw, const float* fcb, float* packed_ws,
                          float* gates0, float* mask0, float* hd0, float* gates1, float* mask1, float* hd1, float p_lstm, float p_fc,
                          uint64_t seed, float* logits, hipStream_t stream);   // ww_head.hip
 
+constexpr int kWg2Partial = WgradCfg<32, 64, 8>::kPartial, kWg3Partial = WgradCfg<64, 128, 4>::kPartial;
+constexpr size_t kWg2Lds = sizeof(float) * WgradCfg<32, 64, 8>::kLdsFloats, kWg3Lds = sizeof(float) * WgradCfg<64, 128, 4>::kLdsFloats;
+constexpr size_t kDg2Lds = sizeof(float) * DgradCfg<32, 64>::kLdsFloats, kDg3Lds = sizeof(float) * DgradCfg<64, 128>::kLdsFloats;
+constexpr int kMaxGroups = 256;                      // grids never exceed the CU count (256 on MI355X)
+
 struct TrainWs {
-    float *mid, *pooled, *gates0, *mask0, *hd0, *gates1, *mask1, *hd1, *lstm_packed, *conv2_b_op, *dgrad_b_op;
-    float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *wg_partial, *dg_partial;
+    float *mid2, *mid3, *dz2, *pooled, *gates0, *mask0, *hd0, *gates1, *mask1, *hd1, *lstm_packed, *conv2_b_op, *conv3_b_op, *dgrad2_b_op, *dgrad3_b_op;
+    float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *partial, *reduced;
     int64_t total;
 };
 static int64_t a256(int64_t floats) { return (floats * 4 + 255) / 256 * 64; }      // floats, 256-byte granules
-static TrainWs carve_train(void* base, int64_t n, int grid_w, int grid_d) {
+static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     TrainWs w{};
     float* p = static_cast<float*>(base);
     int64_t o = 0;
     auto take = [&](int64_t floats) { float* at = p ? p + o : nullptr; o += a256(floats); return at; };
-    w.mid = take(n * kTH * 64 * kTW);
-    w.pooled = take(n * 64);
+    const int c_last = n_conv == 3 ? 128 : 64;
+    w.mid2 = take(n * kTH * 64 * kTW);
+    w.mid3 = n_conv == 3 ? take(n * kTH * 128 * kTW) : nullptr;
+    w.dz2 = n_conv == 3 ? take(n * kTH * 64 * kTW) : nullptr;
+    w.pooled = take(n * c_last);
     w.gates0 = take(4 * n * kHidden); w.mask0 = take(n * kHidden); w.hd0 = take(n * kHidden);
     w.gates1 = take(4 * n * kHidden); w.mask1 = take(n * kHidden); w.hd1 = take(n * kHidden);
-    w.lstm_packed = take((64 + kHidden) * kGateCols + 2 * kGateCols);
+    w.lstm_packed = take((c_last + kHidden) * kGateCols + 2 * kGateCols);
     w.conv2_b_op = take(2 * 144 * 64);
-    w.dgrad_b_op = take(2 * 144 * 64);
+    w.conv3_b_op = n_conv == 3 ? take(4 * 288 * 64) : nullptr;
+    w.dgrad2_b_op = take(2 * 144 * 64);
+    w.dgrad3_b_op = n_conv == 3 ? take(8 * 144 * 64) : nullptr;
     w.dhd1 = take(n * kHidden); w.dg1 = take(n * 4 * kHidden); w.dhd0 = take(n * kHidden); w.dg0 = take(n * 4 * kHidden);
-    w.dpooled = take(n * 64); w.gp = take(n * 64);
-    w.wg_partial = take(int64_t(grid_w) * kWgPartial);
-    w.dg_partial = take(int64_t(grid_d) * kDgPartial);
+    w.dpooled = take(n * c_last); w.gp = take(n * c_last);
+    w.partial = take(int64_t(kMaxGroups) * (n_conv == 3 ? kWg3Partial : kWg2Partial));      // reused by every partial-producing kernel in turn
+    w.reduced = take(n_conv == 3 ? kWg3Partial : kWg2Partial);
     w.total = o * 4;
     return w;
 }
-static void train_grids(int64_t n, int& grid_w, int& grid_d) {
-    const int cus = device_cu_count();
-    grid_w = int(n < cus ? n : cus);                 // one 8-wave workgroup per CU (117 KB of LDS)
-    grid_d = int(n < cus ? n : cus);                 // one 4-wave workgroup per CU (128 KB of LDS)
-}
 
-int64_t train_workspace_bytes(int64_t n) {
-    return carve_train(nullptr, n, 256, 256).total;  // grids never exceed the CU count (256 on MI355X)
-}
+int64_t train_workspace_bytes(int64_t n, int n_conv) { return carve_train(nullptr, n, n_conv).total; }
 
 static int train_opt_in() {
+    static std::mutex mu;
     static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     WW_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
     if (done[dev]) return WW_OK;
-    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(float) * kWgLdsFloats)));
-    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(float) * kDgLdsFloats)));
+    auto opt = [](const void* f, int floats) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, floats * 4); };
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<32, 64, 8, false, true>), WgradCfg<32, 64, 8>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<32, 64, 8, true, true>), WgradCfg<32, 64, 8>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<64, 128, 4, false, false>), WgradCfg<64, 128, 4>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, false, true>), DgradCfg<32, 64>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, true, true>), DgradCfg<32, 64>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false>), DgradCfg<64, 128>::kLdsFloats));
     done[dev] = true;
     return WW_OK;
 }
 
 // test / diagnostic: copies of the dropout factors the last forward on this workspace drew ([n][256] each)
-int train_masks(const void* workspace, int64_t n, float* mask0, float* mask1, hipStream_t st) {
-    TrainWs w = carve_train(const_cast<void*>(workspace), n, 256, 256);
+int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, float* mask1, hipStream_t st) {
+    TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv);
     WW_HIP(hipMemcpyAsync(mask0, w.mask0, sizeof(float) * n * kHidden, hipMemcpyDeviceToDevice, st));
     WW_HIP(hipMemcpyAsync(mask1, w.mask1, sizeof(float) * n * kHidden, hipMemcpyDeviceToDevice, st));
     return WW_OK;
@@ -507,26 +611,41 @@ int train_masks(const void* workspace, int64_t n, float* mask0, float* mask1, hi
 
 int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
                   float* logits, hipStream_t st) {
-    int gw, gd;
-    train_grids(n, gw, gd);
-    if (gw > 256 || gd > 256) return fail(WW_EUNSUPPORTED, "more than 256 CUs: the workspace is sized for 256 partials");
-    TrainWs w = carve_train(workspace, n, 256, 256);
+    if (device_cu_count() > kMaxGroups) return fail(WW_EUNSUPPORTED, "more than 256 CUs: the workspace is sized for 256 partials");
+    const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
+    TrainWs w = carve_train(workspace, n, nc);
     hipLaunchKernelGGL(pack_conv_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], 64, 32, w.conv2_b_op);
     WW_HIP(hipGetLastError());
-    if (int rc = launch_cnn2_f32_mid(mel, n, width, p->conv_weight[0], p->conv_bias[0], w.conv2_b_op, p->conv_bias[1], w.mid, st)) return rc;
-    hipLaunchKernelGGL(pool_mid_kernel, dim3(int(n)), dim3(256), 0, st, w.mid, int(n), width, w.pooled);
-    WW_HIP(hipGetLastError());
-    return launch_lstm_fc_train(w.pooled, n, 64, p->lstm_weight_ih[0], p->lstm_bias_ih[0], p->lstm_bias_hh[0], p->lstm_weight_ih[1],
+    if (int rc = launch_cnn2_f32_mid(mel, n, width, p->conv_weight[0], p->conv_bias[0], w.conv2_b_op, p->conv_bias[1], w.mid2, st)) return rc;
+    if (nc == 3) {
+        hipLaunchKernelGGL(pack_conv_b_dev_kernel, dim3(288), dim3(256), 0, st, p->conv_weight[2], 128, 64, w.conv3_b_op);
+        WW_HIP(hipGetLastError());
+        if (int rc = launch_cnn3_f32_store(w.mid2, n, width, w.conv3_b_op, p->conv_bias[2], w.pooled, w.mid3, st)) return rc;
+    } else {
+        hipLaunchKernelGGL(pool_mid_kernel, dim3(int(n)), dim3(256), 0, st, w.mid2, int(n), width, w.pooled);
+        WW_HIP(hipGetLastError());
+    }
+    return launch_lstm_fc_train(w.pooled, n, c_last, p->lstm_weight_ih[0], p->lstm_bias_ih[0], p->lstm_bias_hh[0], p->lstm_weight_ih[1],
                                 p->lstm_bias_ih[1], p->lstm_bias_hh[1], p->fc_weight, p->fc_bias, w.lstm_packed, w.gates0, w.mask0, w.hd0,
                                 w.gates1, w.mask1, w.hd1, p_lstm, p_fc, seed, logits, st);
+}
+
+// partial[groups][len] -> reduced, then the weight and the bias part go to their gradient tensors
+static int reduce_to(const TrainWs& w, int groups, int len, int w_len, float* dw, float* db, int b_len, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256 < 288 ? (len + 255) / 256 : 288), dim3(256), 0, st, w.partial, groups, len, w.reduced);
+    WW_HIP(hipGetLastError());
+    WW_HIP(hipMemcpyAsync(dw, w.reduced, sizeof(float) * w_len, hipMemcpyDeviceToDevice, st));
+    WW_HIP(hipMemcpyAsync(db, w.reduced + w_len, sizeof(float) * b_len, hipMemcpyDeviceToDevice, st));
+    return WW_OK;
 }
 
 int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
                    const ww_train_grads* g, hipStream_t st) {
     if (int rc = train_opt_in()) return rc;
-    int gw, gd;
-    train_grids(n, gw, gd);
-    TrainWs w = carve_train(workspace, n, 256, 256);
+    const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
+    const int cus = device_cu_count();
+    const int grid = int(n < cus ? n : cus);         // one persistent workgroup per CU (117-149 KB of LDS each)
+    TrainWs w = carve_train(workspace, n, nc);
     const int N = int(n), H = kHidden;
     // fc: dW = dlogits^T hd1, db = colsum(dlogits), dhd1 = dlogits W_fc
     sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st);
@@ -539,27 +658,41 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     sgemm(w.dg1, 4 * H, 1, p->lstm_weight_ih[1], H, 1, w.dhd0, H, N, H, 4 * H, st);            // [n][256] = dg1 W_ih_l1
     // layer 0
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(1024), dim3(256), 0, st, w.dhd0, w.gates0, w.mask0, N, w.dg0);
-    sgemm(w.dg0, 1, 4 * H, w.pooled, 64, 1, g->lstm_weight_ih[0], 64, 4 * H, 64, N, st);       // [1024][64] = dg0^T pooled
+    sgemm(w.dg0, 1, 4 * H, w.pooled, c_last, 1, g->lstm_weight_ih[0], c_last, 4 * H, c_last, N, st);       // [1024][C] = dg0^T pooled
     hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(1024), 0, st, w.dg0, N, 4 * H, g->lstm_bias[0]);
-    sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], 64, 1, w.dpooled, 64, N, 64, 4 * H, st);      // [n][64] = dg0 W_ih_l0
-    hipLaunchKernelGGL(scale_kernel, dim3(256), dim3(256), 0, st, w.dpooled, 1.0f / float(kTH * width), n * 64, w.gp);
+    sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], c_last, 1, w.dpooled, c_last, N, c_last, 4 * H, st);      // [n][C] = dg0 W_ih_l0
+    hipLaunchKernelGGL(scale_kernel, dim3(256), dim3(256), 0, st, w.dpooled, 1.0f / float(kTH * width), n * c_last, w.gp);
     WW_HIP(hipGetLastError());
-    // conv stack
-    hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], w.dgrad_b_op);
-    hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(gw), dim3(512), sizeof(float) * kWgLdsFloats, st, mel, w.mid, w.gp, N, width, p->conv_weight[0],
-                       p->conv_bias[0], w.wg_partial);
-    hipLaunchKernelGGL(conv2_dgrad_kernel, dim3(gd), dim3(256), sizeof(float) * kDgLdsFloats, st, mel, w.mid, w.gp, N, width, p->conv_weight[0],
-                       p->conv_bias[0], w.dgrad_b_op, w.dg_partial);
+    // conv stack, top down.  The last conv feeds the pool (rank-one gradient gp * [act > 0]); below it the gradient is dense.
+    const float* w1 = p->conv_weight[0];
+    const float* b1 = p->conv_bias[0];
+    if (nc == 3) {
+        hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(288), dim3(256), 0, st, p->conv_weight[2], 128, 64, w.dgrad3_b_op);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, false, false>), dim3(grid), dim3(512), kWg3Lds, st,
+                           mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.partial);
+        WW_HIP(hipGetLastError());
+        if (int rc = reduce_to(w, grid, kWg3Partial, 128 * 64 * 9, g->conv_weight[2], g->conv_bias[2], 128, st)) return rc;
+        hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false>), dim3(grid), dim3(512), kDg3Lds, st,
+                           mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
+        WW_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], 64, 32, w.dgrad2_b_op);
+    if (nc == 3)
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, true, true>), dim3(grid), dim3(512), kWg2Lds, st,
+                           mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.partial);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, false, true>), dim3(grid), dim3(512), kWg2Lds, st,
+                           mel, static_cast<const float*>(nullptr), w.mid2, w.gp, N, width, w1, b1, w.partial);
     WW_HIP(hipGetLastError());
-    // partial layout: [64*32*9 dW2][64 db2] and [32*9 dW1][32 db1]: weights and bias are contiguous in the partial, separate in the grads
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(72), dim3(256), 0, st, w.wg_partial, gw, kWgPartial, w.dg1 /*scratch: dg1 is dead now*/);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(256), 0, st, w.dg_partial, gd, kDgPartial, w.dg1 + kWgPartial);
+    if (int rc = reduce_to(w, grid, kWg2Partial, 64 * 32 * 9, g->conv_weight[1], g->conv_bias[1], 64, st)) return rc;
+    if (nc == 3)
+        hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, true, true>), dim3(grid), dim3(256), kDg2Lds, st,
+                           mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.dgrad2_b_op, w.partial);
+    else
+        hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, false, true>), dim3(grid), dim3(256), kDg2Lds, st,
+                           mel, static_cast<const float*>(nullptr), w.mid2, w.gp, N, width, w1, b1, w.dgrad2_b_op, w.partial);
     WW_HIP(hipGetLastError());
-    WW_HIP(hipMemcpyAsync(g->conv_weight[1], w.dg1, sizeof(float) * 64 * 32 * 9, hipMemcpyDeviceToDevice, st));
-    WW_HIP(hipMemcpyAsync(g->conv_bias[1], w.dg1 + 64 * 32 * 9, sizeof(float) * 64, hipMemcpyDeviceToDevice, st));
-    WW_HIP(hipMemcpyAsync(g->conv_weight[0], w.dg1 + kWgPartial, sizeof(float) * 32 * 9, hipMemcpyDeviceToDevice, st));
-    WW_HIP(hipMemcpyAsync(g->conv_bias[0], w.dg1 + kWgPartial + 32 * 9, sizeof(float) * 32, hipMemcpyDeviceToDevice, st));
-    return WW_OK;
+    return reduce_to(w, grid, kDgPartial, 32 * 9, g->conv_weight[0], g->conv_bias[0], 32, st);
 }
 
 }  // namespace ww

@@ -9,10 +9,10 @@ included), same `forward(x[B,1,80,T]) -> logits[B,2]`.  The parameters live in o
 `forward` packs them once per weight version into the kernel layout (MFMA B-operand order, transposed
 W_ih without the dead forget gate, pre-summed biases) and calls `torch.ops.wakeword_amd.cnn_lstm_forward`.
 
-Training: `SimpleWakewordModel` in train mode runs the train-mode forward (inter-layer LSTM dropout,
-dropout before fc) and, through a `torch.autograd.Function`, the HIP backward kernels, so the reference's loop
-(`output = model(data); loss = criterion(output, target); loss.backward(); optimizer.step()`, train_wakeword.py:109-115)
-works unchanged.  The 3-conv `WakewordModel` has no backward kernels yet: its train-mode forward raises.
+Training: in train mode both modules run the train-mode forward (inter-layer LSTM dropout, dropout before
+fc) and, through a `torch.autograd.Function`, the HIP backward kernels, so the reference's loops
+(`output = model(data); loss = criterion(output, target); loss.backward(); optimizer.step()`, train_wakeword.py:109-115,
+WakewordTrainer.train_epoch wakeword_training_script.py:241-267) work unchanged.
 """
 from __future__ import annotations
 
@@ -56,14 +56,12 @@ class _CnnLstm(nn.Module):
 
     def forward(self, x):
         if self.training:
-            if self._n_conv != 2:
-                raise NotImplementedError("training kernels exist for SimpleWakewordModel only; call model.eval() for the 3-conv model")
             if self.fc.weight.device.type != "cuda":
                 raise RuntimeError("model parameters are on the CPU: this path has no CPU implementation; call .to('cuda')")
             # dropout factors come from a counter-based generator; its seed is drawn from torch's CPU generator, so
             # torch.manual_seed() makes a run repeatable
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-            return ops.train_forward(x, dict(self.named_parameters()), float(self.lstm.dropout), float(self.dropout.p), seed)
+            return ops.train_forward(x, dict(self.named_parameters()), self._n_conv, float(self.lstm.dropout), float(self.dropout.p), seed)
         return ops.cnn_lstm_forward(x, self.packed_weights(), self._n_conv)
 
     def forward_pcm(self, pcm, normalize: bool = True):

@@ -236,17 +236,18 @@ def forward_pcm(pcm, packed, n_conv, normalize: bool = True):
 # ------------------------------------------------------------------------------------------------
 # training step (SimpleWakewordModel): train-mode forward + backward on the HIP kernels of csrc/ww_train.hip
 # ------------------------------------------------------------------------------------------------
-_TRAIN_KEYS = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias",
-               "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
-               "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1", "lstm.bias_hh_l1", "fc.weight", "fc.bias")
+def _train_keys(n_conv):
+    convs = [k for i in range(1, n_conv + 1) for k in (f"conv{i}.weight", f"conv{i}.bias")]
+    return tuple(convs + ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
+                          "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1", "lstm.bias_hh_l1", "fc.weight", "fc.bias"])
 
 
-def _train_params_struct(params):
-    c1w, c1b, c2w, c2b, wi0, _wh0, bi0, bh0, wi1, _wh1, bi1, bh1, fw, fb = params
+def _train_params_struct(params, n_conv):
+    convs, (wi0, _wh0, bi0, bh0, wi1, _wh1, bi1, bh1, fw, fb) = params[:2 * n_conv], params[2 * n_conv:]
     tp = nat.TrainParams()
-    tp.n_conv, tp.hidden = 2, 256
-    tp.conv_weight[0], tp.conv_weight[1] = c1w.data_ptr(), c2w.data_ptr()
-    tp.conv_bias[0], tp.conv_bias[1] = c1b.data_ptr(), c2b.data_ptr()
+    tp.n_conv, tp.hidden = n_conv, 256
+    for i in range(n_conv):
+        tp.conv_weight[i], tp.conv_bias[i] = convs[2 * i].data_ptr(), convs[2 * i + 1].data_ptr()
     tp.lstm_weight_ih[0], tp.lstm_weight_ih[1] = wi0.data_ptr(), wi1.data_ptr()
     tp.lstm_bias_ih[0], tp.lstm_bias_ih[1] = bi0.data_ptr(), bi1.data_ptr()
     tp.lstm_bias_hh[0], tp.lstm_bias_hh[1] = bh0.data_ptr(), bh1.data_ptr()
@@ -257,9 +258,11 @@ def _train_params_struct(params):
 class _TrainStep(torch.autograd.Function):
     """logits = model(x) in train mode, with d loss / d parameters from the HIP backward kernels.  `x` gets no gradient (the
     reference never asks for one)."""
+    last_workspace = None
+    last_n_conv = 2
 
     @staticmethod
-    def forward(ctx, x, p_lstm, p_fc, seed, *params):
+    def forward(ctx, x, n_conv, p_lstm, p_fc, seed, *params):
         x = _check_x(x)
         params = tuple(p.detach().contiguous() for p in params)
         for p in params:
@@ -269,38 +272,42 @@ class _TrainStep(torch.autograd.Function):
             raise ValueError("empty training batch")
         logits = torch.empty((B, 2), device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            ws = torch.empty(nat.check(nat.lib.ww_train_workspace_bytes(B, 2)), device=x.device, dtype=torch.uint8)
-            tp = _train_params_struct(params)
+            ws = torch.empty(nat.check(nat.lib.ww_train_workspace_bytes(B, n_conv)), device=x.device, dtype=torch.uint8)
+            tp = _train_params_struct(params, n_conv)
             nat.check(nat.lib.ww_train_forward_f32(_ptr(x), B, T, C.byref(tp), float(p_lstm), float(p_fc), int(seed) & (2 ** 64 - 1),
                                                    _ptr(ws), _ptr(logits), _stream()))
         ctx.save_for_backward(x, ws, *params)
-        _TrainStep.last_workspace = ws
+        ctx.n_conv = n_conv
+        _TrainStep.last_workspace, _TrainStep.last_n_conv = ws, n_conv
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         x, ws, *params = ctx.saved_tensors
+        n_conv = ctx.n_conv
         B, T = x.shape[0], x.shape[3]
         dlogits = dlogits.contiguous().float()
         grads = [torch.empty_like(p) for p in params]
-        grads[5].zero_()                    # weight_hh: h0 = 0, the gradient is exactly zero
-        grads[9].zero_()
+        o = 2 * n_conv                      # index of lstm.weight_ih_l0
+        grads[o + 1].zero_()                # weight_hh: h0 = 0, the gradient is exactly zero
+        grads[o + 5].zero_()
         tg = nat.TrainGrads()
-        tg.conv_weight[0], tg.conv_bias[0], tg.conv_weight[1], tg.conv_bias[1] = (g.data_ptr() for g in grads[:4])
-        tg.lstm_weight_ih[0], tg.lstm_bias[0] = grads[4].data_ptr(), grads[6].data_ptr()
-        tg.lstm_weight_ih[1], tg.lstm_bias[1] = grads[8].data_ptr(), grads[10].data_ptr()
-        tg.fc_weight, tg.fc_bias = grads[12].data_ptr(), grads[13].data_ptr()
+        for i in range(n_conv):
+            tg.conv_weight[i], tg.conv_bias[i] = grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr()
+        tg.lstm_weight_ih[0], tg.lstm_bias[0] = grads[o].data_ptr(), grads[o + 2].data_ptr()
+        tg.lstm_weight_ih[1], tg.lstm_bias[1] = grads[o + 4].data_ptr(), grads[o + 6].data_ptr()
+        tg.fc_weight, tg.fc_bias = grads[o + 8].data_ptr(), grads[o + 9].data_ptr()
         with torch.cuda.device(x.device):
-            tp = _train_params_struct(params)
+            tp = _train_params_struct(params, n_conv)
             nat.check(nat.lib.ww_train_backward_f32(_ptr(x), B, T, C.byref(tp), _ptr(dlogits), _ptr(ws), C.byref(tg), _stream()))
-        grads[7].copy_(grads[6])            # d/d bias_hh == d/d bias_ih
-        grads[11].copy_(grads[10])
-        return (None, None, None, None, *grads)
+        grads[o + 3].copy_(grads[o + 2])    # d/d bias_hh == d/d bias_ih
+        grads[o + 7].copy_(grads[o + 6])
+        return (None, None, None, None, None, *grads)
 
 
-def train_forward(x, named_params: dict, p_lstm: float, p_fc: float, seed: int):
+def train_forward(x, named_params: dict, n_conv: int, p_lstm: float, p_fc: float, seed: int):
     """x [B,1,80,T] + the module's parameters (reference key set) -> logits [B,2] with an autograd graph behind them."""
-    return _TrainStep.apply(x, p_lstm, p_fc, seed, *[named_params[k] for k in _TRAIN_KEYS])
+    return _TrainStep.apply(x, n_conv, p_lstm, p_fc, seed, *[named_params[k] for k in _train_keys(n_conv)])
 
 
 def train_last_masks(n: int):
@@ -309,7 +316,7 @@ def train_last_masks(n: int):
     m0 = torch.empty((n, 256), device=ws.device, dtype=torch.float32)
     m1 = torch.empty_like(m0)
     with torch.cuda.device(ws.device):
-        nat.check(nat.lib.ww_train_masks(_ptr(ws), n, _ptr(m0), _ptr(m1), _stream()))
+        nat.check(nat.lib.ww_train_masks(_ptr(ws), n, _TrainStep.last_n_conv, _ptr(m0), _ptr(m1), _stream()))
     return m0, m1
 
 
