@@ -368,6 +368,7 @@ def main():
             # one training step of the same model (forward in train mode + backward + Adam)
             import bench_train
             out["training"] = bench_train.measure(batch=B, steps=5, device=dev.index)
+            out["training_3conv"] = bench_train.measure(batch=2048, steps=3, device=dev.index, arch="full", cpu_sample=16)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

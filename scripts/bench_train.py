@@ -11,12 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(batch=4096, steps=5, device=0, cpu_sample=64):
+def measure(batch=4096, steps=5, device=0, cpu_sample=64, arch="simple"):
     import wakeword_jupyterlab_amd as pkg
     from oracle import model_oracle
     dev = torch.device("cuda", device)
-    sd = pkg.synth.make_state_dict("simple", seed=1234)
-    m = pkg.SimpleWakewordModel()
+    sd = pkg.synth.make_state_dict(arch, seed=1234)
+    m = pkg.SimpleWakewordModel() if arch == "simple" else pkg.WakewordModel()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m = m.to(dev).train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
@@ -48,11 +48,11 @@ def measure(batch=4096, steps=5, device=0, cpu_sample=64):
         crit(ref(xc), yc).backward()
         opt_r.step()
     dt_cpu = (time.perf_counter() - t1) / 2
-    return {"workload": f"SimpleWakewordModel training step (train-mode forward with dropout 0.5/0.5 + CrossEntropyLoss + backward + Adam), "
+    return {"workload": f"{'SimpleWakewordModel' if arch == 'simple' else '3-conv WakewordModel'} training step (train-mode forward with dropout + CrossEntropyLoss + backward + Adam), "
                         f"batch {batch}, log-mel inputs resident in HBM; exact fp32 kernels (csrc/ww_train.hip)",
             "ms_per_step": dt * 1e3, "clips_per_s": batch / dt, "final_loss": float(loss.item()),
             "cpu_torch_clips_per_s": cpu_sample / dt_cpu, "cpu_threads": int(torch.get_num_threads()), "cpu_sample": cpu_sample}
 
 
 if __name__ == "__main__":
-    print(measure())
+    print(measure(arch=sys.argv[1] if len(sys.argv) > 1 else "simple", batch=int(sys.argv[2]) if len(sys.argv) > 2 else 4096))
