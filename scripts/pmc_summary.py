@@ -46,7 +46,7 @@ for k in sorted(sq):
     if d.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
         # GRBM_GUI_ACTIVE sums the 8 XCDs; MFMA busy sums 256 CUs x 4 SIMDs
         d["mfma_pipe_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
-out["algorithmic_bytes_per_launch"] = {"ww::logmel_kernel<false>": 4096 * 74240, "ww::cnn2h16_kernel<true>": 4096 * (80 * 32 * 4 + 64 * 4) + 1047040}
+out["algorithmic_bytes_per_launch"] = {"ww::logmel_kernel<false>": 4096 * 74240, "ww::cnn2w_kernel<true> / cnn2h16_kernel<true>": 4096 * (80 * 32 * 4 + 64 * 4) + 1047040}
 json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
 for name, dst in (("stats/*kernel_stats.csv", "_bench_kernel_stats.csv"), ("pmc_fetch/*counter_collection.csv", "_pmc_fetch_counter_collection.csv"),
                   ("pmc_write/*counter_collection.csv", "_pmc_write_counter_collection.csv"), ("pmc_sq/*counter_collection.csv", "_pmc_sq_counter_collection.csv")):
