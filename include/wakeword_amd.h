@@ -12,8 +12,8 @@
  *     pointer is ordinary host memory.  No torch / C++ types cross this boundary.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All launch
  *     functions are asynchronous on that stream, allocate nothing, never synchronise and are
- *     therefore capturable into a hipGraph once ww_init() has run on the device (exceptions, stated
- *     at the function: ww_augment_f32 reads its plans from host memory and synchronises the stream).
+ *     therefore capturable into a hipGraph once ww_init() has run on the device (exception, stated
+ *     at the function: ww_augment_f32 reads its plans from host memory and is not capturable).
  *   - return value: WW_OK (0) or a negative WW_E* code; ww_last_error() gives the message of the
  *     calling thread's most recent failure.  Nothing falls back to a CPU path: without a usable
  *     gfx950 device every launch function fails with WW_ENODEVICE.
@@ -161,8 +161,8 @@ typedef struct ww_augment_plan {
 } ww_augment_plan;
 WW_API int64_t ww_augment_workspace_bytes(int64_t n_clips);
 /* pcm_dev [n_clips] rows of 16000 samples at pcm_dev + i*clip_stride (16-byte aligned, clip_stride % 4 == 0);
- * plans_host [n_clips] in HOST memory (uploaded and the stream synchronised before the call returns: not graph-
- * capturable); out_dev [n_clips][16000], may alias pcm_dev;
+ * plans_host [n_clips] in HOST memory: read before the call returns (staged through pinned memory owned by the library, so
+ * the call is asynchronous on `stream`; it is not graph-capturable); out_dev [n_clips][16000], may alias pcm_dev;
  * workspace_dev >= ww_augment_workspace_bytes(n_clips), 256-byte aligned. */
 WW_API int ww_augment_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, const ww_augment_plan* plans_host,
                    float* out_dev, void* workspace_dev, ww_stream_t stream);

@@ -19,6 +19,8 @@
 //   noise_kernel      + sigma * normal(seed, i), the build's counter-based generator (splitmix64 -> Box-Muller)
 // Clips whose plan switches a transform off skip its kernels (their blocks copy the data through).
 #include <cmath>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ww_fft.h"
@@ -309,6 +311,18 @@ int64_t augment_workspace_bytes(int64_t n) {
            up256(n * int64_t(kAugMaxOut) * kSpec * 8) + up256(n * int64_t(kAugYStride) * 4);
 }
 
+// Pinned staging for the per-clip records: two slots per device, each guarded by an event, so the call can return as soon as the
+// copy and the kernels are enqueued (round 1 synchronised the stream because the records lived in a pageable vector).
+struct PlanStage {
+    AugDev* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool in_use = false;
+};
+static std::mutex g_stage_mu;
+static PlanStage g_stage[16][2];
+static int g_stage_next[16] = {};
+
 int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment_plan* plans_host, float* out,
                    int64_t out_stride, void* workspace, hipStream_t stream) {
     if (n == 0) return WW_OK;
@@ -360,8 +374,27 @@ int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment
     float2* D = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugFrames) * kSpec * 8);
     float2* S = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugMaxOut) * kSpec * 8);
     float* Y = reinterpret_cast<float*>(w);
-    WW_HIP(hipMemcpyAsync(plan, host.data(), size_t(n) * sizeof(AugDev), hipMemcpyHostToDevice, stream));
-    WW_HIP(hipStreamSynchronize(stream));     // `host` is pageable and dies with this frame
+    {
+        int dev = 0;
+        WW_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16) return fail(WW_EUNSUPPORTED, "device ordinal %d out of range", dev);
+        std::lock_guard<std::mutex> lock(g_stage_mu);
+        PlanStage& st = g_stage[dev][g_stage_next[dev]];
+        g_stage_next[dev] ^= 1;
+        if (st.in_use) WW_HIP(hipEventSynchronize(st.ev));          // the copy that last read this slot (two calls ago) must be done
+        if (st.cap < size_t(n)) {
+            if (st.host) WW_HIP(hipHostFree(st.host));
+            st.host = nullptr;
+            st.cap = 0;
+            WW_HIP(hipHostMalloc(reinterpret_cast<void**>(&st.host), size_t(n) * sizeof(AugDev), hipHostMallocDefault));
+            st.cap = size_t(n);
+        }
+        if (!st.ev) WW_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        std::memcpy(st.host, host.data(), size_t(n) * sizeof(AugDev));
+        WW_HIP(hipMemcpyAsync(plan, st.host, size_t(n) * sizeof(AugDev), hipMemcpyHostToDevice, stream));
+        WW_HIP(hipEventRecord(st.ev, stream));
+        st.in_use = true;
+    }
 
     static bool attr[64] = {};
     int dev = 0;

@@ -811,7 +811,10 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
         asm volatile("" : "+v"(w1h_r), "+v"(w1l_r));
         const half8 a1h = __builtin_bit_cast(half8, w1h_r), a1l = __builtin_bit_cast(half8, w1l_r);
         const GatherLanes glanes = gather_lanes(lane & 31, lane >> 5);
-        __builtin_amdgcn_s_setprio(3);
+#ifndef WW_WINO_PPRIO
+#define WW_WINO_PPRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(WW_WINO_PPRIO);
         const float rng_l1 = rng[0], rng_b1 = rng[1];
         const int s1_exp = -exp_of(hs1[0]);
         // model input of clip k -> two f16 planes of x * 2^-e (see cnn2h16_kernel).  All four producers meet inside (the xmax
@@ -936,6 +939,9 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
         const float bias = b2[16 * nt + pi];
         const float descale = 0.5f * hs[16 * nt + pi];
         float dsc = descale, pool = 0.f;
+#ifdef WW_WINO_CPRIO
+        __builtin_amdgcn_s_setprio(WW_WINO_CPRIO);
+#endif
         const int gsteps = my_clips * kWPerGroup;
         for (int q = 0; q < gsteps; ++q) {
             const int k = q / kWPerGroup, sq = q - k * kWPerGroup;
