@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 1
+#define WW_ABI_VERSION 2 /* 2: ww_set_logmel_math, ww_train_*, third conv-math mode (round 2) */
 
 #if defined(WW_BUILD)
 #define WW_API __attribute__((visibility("default")))

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WW_LIB_OVERRIDE") or os.path.join(_HERE, "libwakeword_amd.so")   # override: ablation builds only
 
 WW_OK, WW_EINVAL, WW_ENODEVICE, WW_EHIP, WW_EUNSUPPORTED = 0, -1, -2, -3, -4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NativeError(RuntimeError):
