@@ -55,14 +55,17 @@ def pmc_traffic(kernel, batch, arch):
     WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process;
     the newest committed pass for this batch/arch is quoted, else null."""
     import glob
-    if batch != 4096 or arch != "simple":
+    if batch != 4096:
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    pattern = "r*_pmc_traffic.json" if arch == "simple" else "r*_full_pmc_traffic.json"      # the 3-conv passes are kept in files of their own
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        if arch == "simple" and "_full_" in path:
+            continue
         try:
             k = json.load(open(path))["kernels"]
-            for name, d in k.items():
-                if kernel in name:
-                    return d["hbm_bytes_per_launch_corrected"]
+            hits = [d["hbm_bytes_per_launch_corrected"] for name, d in k.items() if any(part in name for part in kernel.split("+"))]
+            if hits:
+                return sum(hits)                     # "a+b": the stage is two launches (conv2 kernel + conv3 kernel)
         except Exception:
             continue
     return None
@@ -284,7 +287,7 @@ def main():
         k2_flops = K2_FLOPS_PER_CLIP[args.arch] * B
         k2_ach = k2_flops / (k2_ms * 1e-3)
         split = conv_math in ("f16x3", "f16x3d")
-        wino = conv_math == "f16x3" and args.arch == "simple"
+        wino = conv_math == "f16x3"            # conv2 (and conv3 of the 3-conv model) as 1-D Winograd F(2,3)
         # matrix-pipe flops actually issued per algorithmic flop: 3 (split) x 2/3 for conv2 as Winograd F(2,3) along rows
         issue_mult = (3.0 * (2.0 / 3.0 if wino else 1.0)) if split else 1.0
         k2_peak = MFMA_F16_PEAK if split else MFMA_F32_PEAK
@@ -306,9 +309,12 @@ def main():
                 "kernel": ("cnn2w_kernel (conv1 + conv2 + ReLU + avg-pool; conv2 as 1-D Winograd F(2,3) along rows, split-precision v_mfma_f32_16x16x32_f16 x3)" if wino else
                            "cnn2h16_kernel (conv1 + conv2 + ReLU + avg-pool; split-precision v_mfma_f32_16x16x32_f16 x3)" if split else
                            "cnn2_kernel<POOL> (conv1 + conv2 + ReLU + avg-pool, v_mfma_f32_32x32x2_f32)") if args.arch == "simple"
-                          else "cnn2 + cnn3 kernels (conv stack)",
+                          else ("cnn2w_kernel<false> + cnn3w_kernel (conv stack of the 3-conv model, both convs as 1-D Winograd, float32 intermediate in HBM)" if wino else
+                                "cnn2h16_kernel<false> + cnn3h_kernel (direct split-precision convs, f16 hi/lo intermediate in HBM)" if split else
+                                "cnn2_kernel<false> + cnn3_kernel (exact f32)"),
                 "bound": "mfma", "achieved": k2_ach / 1e12, "peak": k2_peak / 1e12, "unit": "TFLOP/s",
-                "frac": k2_ach / k2_peak, "traffic": pmc_traffic("cnn2w_kernel" if wino else "cnn2h16_kernel" if split else "cnn2_kernel", B, args.arch),
+                "frac": k2_ach / k2_peak, "traffic": pmc_traffic(("cnn2w_kernel" if wino else "cnn2h16_kernel" if split else "cnn2_kernel") if args.arch == "simple" else
+                                                 ("cnn2w_kernel+cnn3w_kernel" if wino else "cnn2h16_kernel+cnn3h_kernel" if split else "cnn2_kernel+cnn3_kernel"), B, args.arch),
                 "flops_per_launch": k2_flops, "avg_launch_ms": k2_ms,
                 "note": (f"achieved = ALGORITHMIC fp32 flops of the direct convolution; the kernel issues {issue_mult:.1f} f16 MFMA flops per "
                          "algorithmic flop (3 per product block for fp32-level accuracy"
