@@ -116,6 +116,22 @@ def test_logmel_noise_free_signals_meet_the_tolerance_over_the_whole_range(ops, 
     assert np.all(out.max(axis=(1, 2, 3)) == 0.0) and out.min() >= -80.0
 
 
+@pytest.mark.parametrize("n", [1, 511, 9000, 16000])
+def test_logmel_f64_mode_short_clips_and_strides(ops, dev, n):
+    x = pkg.synth.make_clips(100, 3)[:, :n].copy()
+    x[1] *= 0.01
+    ops.set_logmel_math("f64")
+    try:
+        out = ops.logmel(torch.from_numpy(x).to(dev), True).cpu().numpy()
+        raw = ops.logmel(torch.from_numpy(x).to(dev), False).cpu().numpy()
+        one = ops.logmel(torch.from_numpy(x[2:3]).to(dev), True).cpu().numpy()
+    finally:
+        ops.set_logmel_math("auto")
+    assert np.abs(out - mel_oracle.logmel_batch(x, normalize=True)).max() <= MEL_TOL
+    assert np.abs(raw - mel_oracle.logmel_batch(x, normalize=False)).max() <= MEL_TOL
+    assert np.array_equal(one[0], out[2])
+
+
 def test_logmel_f32_mode_floor_and_auto_leaves_noisy_clips_alone(ops, dev, clips64, ref_mel64):
     """The float32 kernel alone: within tolerance down to -60 dB on noise-free signals, ~3e-4 dB on its rounding floor below
     (recorded, not the shipped default).  Auto mode must not touch clips with a broadband floor: the benchmark's clips

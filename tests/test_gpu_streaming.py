@@ -70,6 +70,34 @@ def test_streaming_partial_window_is_zero_padded_on_the_left_and_silence_is_nan(
     det.close()
 
 
+def test_streaming_clean_tone_goes_through_the_float64_path():
+    """A microphone carrying a noise-free tone: its windows sit on the float FFT's rounding floor, so the captured per-hop graph's
+    second log-mel launch (auto mode: the float64 kernel in ring mode, marked clips only) must redo them -- logits against the
+    windowed oracle like any other microphone."""
+    dev = torch.device("cuda", 0)
+    sd = pkg.synth.make_state_dict("simple", seed=1234)
+    m = pkg.SimpleWakewordModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    hop, n_hops = 400, 55
+    t = np.arange(n_hops * hop) / 16000.0
+    streams = np.stack([0.5 * np.sin(2 * np.pi * 440.0 * t), pkg.synth.make_clips(3, 2).reshape(-1)[: n_hops * hop],
+                        0.3 * np.sin(2 * np.pi * 1234.5 * t) * (t > 0.4)]).astype(np.float32)
+    det = pkg.StreamingDetector(m, n_mics=3, hop_samples=hop)
+    for k in range(n_hops):
+        det.step(torch.from_numpy(streams[:, k * hop:(k + 1) * hop]).to(dev))
+        if k in (20, 39, 54):
+            det.stream.synchronize()
+            done = (k + 1) * hop
+            win = np.zeros((3, 16000), np.float32)
+            seg = streams[:, max(0, done - 16000):done]
+            win[:, 16000 - seg.shape[1]:] = seg
+            ref_mel = mel_oracle.logmel_batch(win, normalize=True)
+            ref = model_oracle.forward_np(ref_mel, sd)
+            assert np.abs(det.logits.cpu().numpy() - ref).max() <= 1e-3
+    det.close()
+
+
 def test_streamer_rejects_bad_hops():
     from wakeword_jupyterlab_amd import _native as nat
     dev = torch.device("cuda", 0)
