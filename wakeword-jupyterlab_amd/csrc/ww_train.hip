@@ -16,7 +16,7 @@
 // a1 = relu(conv1) is recomputed from the log-mel tile where it is needed (0.74 MMAC per clip) instead of being stored.
 // The forward keeps relu(conv2) (the exact-f32 cnn2_kernel<false> of ww_cnn.hip), the gate activations and dropout factors.
 // The LSTM step with zero state has the closed form of ww_head.hip; its backward is elementwise (lstm_gates_bwd_kernel) plus
-// six small GEMMs (sgemm_kernel).  W_hh gradients are exactly zero (h0 = 0) and are left to the caller to zero-fill.
+// six small GEMMs (mfma_gemm_kernel).  W_hh gradients are exactly zero (h0 = 0) and are left to the caller to zero-fill.
 // Every reduction over clips runs in a fixed order (per-workgroup partials + reduce_partials_kernel): bitwise repeatable.
 #include <mutex>
 
@@ -481,50 +481,63 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// C[M][N] = sum_k A(m,k) B(k,n) with general strides (the six small GEMMs of the head's backward: M*N*K <= 1.1e9).
-// T x T tiles (T = 64: 4x4 outputs per thread; T = 32: 2x2, four times the workgroups for the K = batch weight-gradient GEMMs),
-// 256 threads, K in steps of 16 through LDS; fp32 FMA, fixed order.
+// C[M][N] = sum_k A(m,k) B(k,n) with general strides (the six small GEMMs of the head's backward: M*N*K <= 1.1e9) on
+// v_mfma_f32_32x32x2_f32, exact fp32.  A workgroup of 4 waves owns a 32 x 32 tile of C; wave w takes the k pairs w, w + 4, ...
+// (neighbouring k of the four waves share cache lines where k is the contiguous index), operands straight from global memory
+// (one dword per lane and MFMA for each: A lane = (m, k parity), B lane = (n, k parity)); the four partial tiles are summed
+// through LDS in the fixed order 0, 1, 2, 3.  Rows / columns beyond M / N load zeros and are not stored.
 // ------------------------------------------------------------------------------------------------
-template <int T>
-__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B, int64_t sbk,
-                                                    int64_t sbn, float* __restrict__ C, int64_t ldc, int M, int N, int K) {
-    constexpr int R = T / 16;
-    __shared__ float As[16][T + 1], Bs[16][T + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
-    float acc[R][R] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int i = threadIdx.x; i < 16 * T; i += 256) {
-            const int kk = i / T, mm = i - kk * T;              // consecutive threads walk m (or n)
-            As[kk][mm] = (m0 + mm < M && k0 + kk < K) ? A[int64_t(m0 + mm) * sam + int64_t(k0 + kk) * sak] : 0.f;
-            Bs[kk][mm] = (n0 + mm < N && k0 + kk < K) ? B[int64_t(k0 + kk) * sbk + int64_t(n0 + mm) * sbn] : 0.f;
+__global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B,
+                                                        int64_t sbk, int64_t sbn, float* __restrict__ C, int64_t ldc, int M, int N, int K) {
+    __shared__ float xch[3][16][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mn = lane & 31, kk = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const bool a_ok = m0 + mn < M, b_ok = n0 + mn < N;
+    const float* ap = A + int64_t(a_ok ? m0 + mn : 0) * sam;
+    const float* bp = B + int64_t(b_ok ? n0 + mn : 0) * sbn;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int pairs = (K + 1) / 2;
+    int p = wave;
+    for (; p + 28 < pairs; p += 32) {                        // eight k pairs per trip: sixteen loads in flight under the MFMAs
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = 2 * (p + 4 * u) + kk;
+            const bool k_ok = k < K;
+            a[u] = (a_ok && k_ok) ? ap[int64_t(k) * sak] : 0.f;
+            b[u] = (b_ok && k_ok) ? bp[int64_t(k) * sbk] : 0.f;
         }
-        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float a[R], b[R];
-#pragma unroll
-            for (int i = 0; i < R; ++i) { a[i] = As[kk][ty * R + i]; b[i] = Bs[kk][tx * R + i]; }
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int j = 0; j < R; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
+    for (; p < pairs; p += 4) {
+        const int k = 2 * p + kk;
+        const bool k_ok = k < K;
+        const float a = (a_ok && k_ok) ? ap[int64_t(k) * sak] : 0.f;
+        const float b = (b_ok && k_ok) ? bp[int64_t(k) * sbk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < 16; ++j) xch[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (m0 + ty * R + i < M && n0 + tx * R + j < N) C[int64_t(m0 + ty * R + i) * ldc + n0 + tx * R + j] = acc[i][j];
+        for (int j = 0; j < 16; ++j) {
+            const float v = ((acc[j] + xch[0][j][lane]) + xch[1][j][lane]) + xch[2][j][lane];
+            const int m = m0 + (j & 3) + 8 * (j >> 2) + 4 * kk;          // D: lane & 31 = n, register j <-> row m
+            if (m < M && b_ok) C[int64_t(m) * ldc + n0 + mn] = v;
+        }
+    }
 }
 
 static void sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int M, int N, int K,
                   hipStream_t st) {
-    if (int64_t(M) * N <= 512 * 512)     // few output tiles (the weight gradients, K = batch): small tiles, more workgroups
-        hipLaunchKernelGGL(sgemm_kernel<32>, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K);
-    else
-        hipLaunchKernelGGL(sgemm_kernel<64>, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K);
+    hipLaunchKernelGGL(mfma_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K);
 }
 
 // gp[b][co] = dpooled[b][co] / (80 * width)
