@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 2 /* 2: ww_set_logmel_math, ww_train_*, third conv-math mode (round 2) */
+#define WW_ABI_VERSION 3 /* 2: ww_set_logmel_math, ww_train_*, third conv-math mode; 3: ww_set_train_math (round 2) */
 
 #if defined(WW_BUILD)
 #define WW_API __attribute__((visibility("default")))
@@ -273,6 +273,15 @@ WW_API int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width,
 /* Diagnostic: the dropout factors (0 or 1 / (1 - p)) the last forward on this workspace applied to the layer-0 output and to
  * fc's input, [n][256] each -- lets a test replay the step in another framework with the same masks. */
 WW_API int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, float* mask0_dev, float* mask1_dev, ww_stream_t stream);
+/* Arithmetic of the training step's convolution kernels, process-wide (the head is always exact fp32):
+ *   WW_TRAIN_MATH_F32    exact fp32 matrix instructions throughout (v_mfma_f32_32x32x2_f32)
+ *   WW_TRAIN_MATH_F16X3  (default) split precision on the f16 matrix instructions wherever a kernel exists (SimpleWakewordModel's conv2
+ *                        backward: one operand is the 0/1 ReLU mask, exact in f16; the other is carried as two f16 halves); the
+ *                        remaining kernels run as under F32.  Gradients agree with F32 to the 2^-22 of the split. */
+#define WW_TRAIN_MATH_F32 0
+#define WW_TRAIN_MATH_F16X3 1
+WW_API int ww_set_train_math(int mode);
+WW_API int ww_get_train_math(void);
 
 /* ---- streaming: sliding 1 s window, one hop per step, many microphones ------------------------ */
 /* Semantics per window = predict_wakeword (wakeword_training.ipynb cell 19): normalise the last

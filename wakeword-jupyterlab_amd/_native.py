@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WW_LIB_OVERRIDE") or os.path.join(_HERE, "libwakeword_amd.so")   # override: ablation builds only
 
 WW_OK, WW_EINVAL, WW_ENODEVICE, WW_EHIP, WW_EUNSUPPORTED = 0, -1, -2, -3, -4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NativeError(RuntimeError):
@@ -83,6 +83,8 @@ PROTOTYPES = {
     "ww_init": (C.c_int, []),
     "ww_set_conv_math": (C.c_int, [C.c_int]),
     "ww_get_conv_math": (C.c_int, []),
+    "ww_set_train_math": (C.c_int, [C.c_int]),
+    "ww_get_train_math": (C.c_int, []),
     "ww_set_logmel_math": (C.c_int, [C.c_int]),
     "ww_get_logmel_math": (C.c_int, []),
     "ww_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),

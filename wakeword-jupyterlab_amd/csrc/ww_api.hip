@@ -69,6 +69,8 @@ const LogmelTables* device_tables() {
 }
 
 static int g_conv_math = WW_CONV_MATH_F16X3;
+static int g_train_math = WW_TRAIN_MATH_F16X3;
+int train_math_mode() { return g_train_math; }
 int conv_math_mode() { return g_conv_math; }
 void set_conv_math_mode(int mode) { g_conv_math = mode; }
 
@@ -194,6 +196,12 @@ int ww_set_conv_math(int mode) {
     return WW_OK;
 }
 int ww_get_conv_math(void) { return conv_math_mode(); }
+int ww_set_train_math(int mode) {
+    if (mode != WW_TRAIN_MATH_F32 && mode != WW_TRAIN_MATH_F16X3) return fail(WW_EINVAL, "train math %d: expected WW_TRAIN_MATH_F32 or WW_TRAIN_MATH_F16X3", mode);
+    g_train_math = mode;
+    return WW_OK;
+}
+int ww_get_train_math(void) { return g_train_math; }
 
 int ww_set_logmel_math(int mode) {
     if (mode != WW_LOGMEL_MATH_F32 && mode != WW_LOGMEL_MATH_F64 && mode != WW_LOGMEL_MATH_AUTO)

@@ -138,6 +138,11 @@ int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, floa
 int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
                    const ww_train_grads* g, hipStream_t st);
 
+int train_math_mode();   // 0 exact fp32, 1 split-precision conv backward where a kernel exists (ww_train_h.hip)
+int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st);
+int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* w1, const float* b1,
+                         float* partial, int grid, hipStream_t st);
+
 int require_gfx950();
 int device_cu_count();   // CUs of the current device (256 on MI355X); cached
 

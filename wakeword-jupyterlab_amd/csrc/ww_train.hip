@@ -565,6 +565,7 @@ constexpr int kMaxGroups = 256;                      // grids never exceed the C
 struct TrainWs {
     float *mid2, *mid3, *dz2, *pooled, *gates0, *mask0, *hd0, *gates1, *mask1, *hd1, *lstm_packed, *conv2_b_op, *conv3_b_op, *dgrad2_b_op, *dgrad3_b_op;
     float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *partial, *reduced;
+    uint32_t* maskbits;                                  // [n][80][32][c_last / 32]: [relu(last conv) > 0]
     int64_t total;
 };
 static int64_t a256(int64_t floats) { return (floats * 4 + 255) / 256 * 64; }      // floats, 256-byte granules
@@ -589,6 +590,7 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     w.dpooled = take(n * c_last); w.gp = take(n * c_last);
     w.partial = take(int64_t(kMaxGroups) * (n_conv == 3 ? kWg3Partial : kWg2Partial));      // reused by every partial-producing kernel in turn
     w.reduced = take(n_conv == 3 ? kWg3Partial : kWg2Partial);
+    w.maskbits = reinterpret_cast<uint32_t*>(take(n * kTH * kTW * (c_last / 32)));
     w.total = o * 4;
     return w;
 }
@@ -660,6 +662,7 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const int grid = int(n < cus ? n : cus);         // one persistent workgroup per CU (117-149 KB of LDS each)
     TrainWs w = carve_train(workspace, n, nc);
     const int N = int(n), H = kHidden;
+    const bool split = train_math_mode() == WW_TRAIN_MATH_F16X3 && nc == 2;      // the kernels of ww_train_h.hip
     // fc: dW = dlogits^T hd1, db = colsum(dlogits), dhd1 = dlogits W_fc
     sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st);
     hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, st, dlogits, N, 2, g->fc_bias);
@@ -693,7 +696,10 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     if (nc == 3)
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, true, true>), dim3(grid), dim3(512), kWg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.partial);
-    else
+    else if (split) {
+        if (int rc = launch_relu_mask_bits(w.mid2, n, 64, w.maskbits, st)) return rc;
+        if (int rc = launch_conv2_wgrad_h(mel, w.maskbits, w.gp, n, width, w1, b1, w.partial, grid, st)) return rc;
+    } else
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, false, true>), dim3(grid), dim3(512), kWg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.mid2, w.gp, N, width, w1, b1, w.partial);
     WW_HIP(hipGetLastError());

@@ -1,0 +1,362 @@
+// Split-precision (f16 matrix-core) backward kernels of the LAST convolution of SimpleWakewordModel:
+// the weight gradient and the data gradient of conv2, the two kernels that take 60 % of the exact-fp32 training step.
+//
+// What is computed is the same as in ww_train.hip (/root/reference/wakeword_training/train_wakeword.py:109-115, loss.backward()):
+//     dW2[co][ci][dy][dx] = sum_b gp[b,co] * S[b][co][ci][dy][dx],     S = sum_{y,x} mask[b,co,y,x] * a1[b,ci,y+dy-1,x+dx-1]
+//     da1[b,ci,y,x]       = sum_{co,dy,dx} mask[b,co,y-dy+1,x-dx+1] * (gp[b,co] * W2[co][ci][dy][dx])
+// with mask = [relu(conv2) > 0] and gp = d loss / d pooled / (80 T): the last conv's gradient is rank one, so ONE operand of either
+// product is a 0/1 matrix -- exact in f16.  The other operand (a1, or gp * W2 rebuilt per clip) is carried as two f16 halves
+// (x * 2^-e = hi + lo, 22 bits), every product block is TWO v_mfma_f32_16x16x32_f16 (mask * hi + mask * lo), all products are exact in
+// the fp32 accumulator and gp enters in fp32: the result differs from the exact-fp32 kernels only by the 2^-22 of the split and by
+// the accumulation order.  16x the matrix rate of v_mfma_f32_32x32x2_f32 at 2 instead of 1 instructions per product.
+//
+// The mask travels as BITS: maskbits[b][row][col] = COUT bits (bit c of the position's word(s) = [relu(conv)[c] > 0]), 20 KB per clip
+// instead of the 655 KB of the float activations.
+#include "ww_internal.h"
+
+namespace ww {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2_t = __attribute__((ext_vector_type(2))) _Float16;
+using float2_t = __attribute__((ext_vector_type(2))) float;
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+constexpr int kTH = WW_N_MELS, kTW = 32;
+constexpr int kTMelRS = 36, kTMelFloats = (kTH + 2) * kTMelRS;   // log-mel tile with a zero halo (as in ww_train.hip)
+
+__device__ __forceinline__ int exp_of_h(float v) { return int((__float_as_uint(v) >> 23) & 0xffu) - 127; }
+__device__ __forceinline__ int clampi_h(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float pow2i_h(int e) { return __uint_as_float(uint32_t(127 + e) << 23); }
+// x ~= hi + lo for two values at once (the forward kernels' split2)
+__device__ __forceinline__ void split2_h(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const float2_t v = {a, b};
+    const half2_t h = __builtin_convertvector(v, half2_t);
+    const float2_t r = {__builtin_fmaf(static_cast<float>(h[0]), -1.0f, a), __builtin_fmaf(static_cast<float>(h[1]), -1.0f, b)};
+    const half2_t l = __builtin_convertvector(r, half2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+// ds_read_b64_tr_b16: within a group of 16 lanes, lane 4q + p supplies the address of row q, 16-bit columns 4p .. 4p+3 of a 4 x 16 block;
+// lane i receives column i, row q in element q (scripts/ubench/tr_read.hip).  EXEC must be all ones.
+__device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p));
+}
+__device__ __forceinline__ half8 cat8(fp16x4 a, fp16x4 b) {
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    const u32x4 v = {ua[0], ua[1], ub[0], ub[1]};
+    return __builtin_bit_cast(half8, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// relu(conv) [b][row][C][32 columns] floats (cnn2_kernel<false> / cnn3_kernel<STORE>) -> mask bits [b][row][32 columns][C/32 words].
+// One workgroup of C threads per (clip, row): thread = channel reads its 32 columns, one ballot per column.
+// ------------------------------------------------------------------------------------------------
+__global__ void relu_mask_bits_kernel(const float* __restrict__ act, int C, uint32_t* __restrict__ bits) {
+    const int64_t row = blockIdx.x;                               // clip * 80 + image row
+    const int ch = threadIdx.x, lane = ch & 63, wv = ch >> 6;
+    const float4* src = reinterpret_cast<const float4*>(act + (row * C + ch) * kTW);
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float4 q = src[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(v[c] > 0.f);
+        if (lane == c) mine = m;
+    }
+    if (lane < 32) {
+        uint32_t* o = bits + (row * kTW + lane) * (C / 32) + 2 * wv;
+        o[0] = uint32_t(mine);
+        o[1] = uint32_t(mine >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of conv2 (32 -> 64) with relu(conv1) recomputed from the log-mel tile.
+//   D[m = co][n = ci] += A[m][k] B[k][n] on v_mfma_f32_16x16x32_f16, k = the 32 columns of one image row:
+//   A = mask row y (exact), B = a1 row y + dy - 1 shifted by dx - 1 (hi, lo): S[dy][dx] += A_y (B_hi + B_lo).
+// Both operands sum over POSITIONS while the LDS tiles are channels-last records (one record per position, so that the dx shift is a
+// record offset): the fragments come in through ds_read_b64_tr_b16, the transposing read.  The k <-> column map is a free choice (the
+// same for A and B): lane group g, element j takes column 8g + 2j (first read) / 8g + 2j + 1 (second read), which makes every read's
+// eight rows tile the 64 banks exactly with 144-byte records.
+// 12 waves, one workgroup per CU, persistent over clips:
+//   waves 0-7   CONSUMERS = (16 co) x (16 ci): nine 16x16 accumulators S (one per tap) for the current clip, nine more for
+//               dW = sum_b gp[b,co] 2^a S_b (fp32, added at the end of every clip: gp never meets f16), one for the bias count;
+//               per a1 row: 3 x 2 B fragments (12 transposed reads), one new mask row (2 reads; the rows y-1, y, y+1 roll through
+//               registers), 18 + 1 MFMAs;
+//   waves 8-11  PRODUCERS: per step of four rows, conv1 + ReLU on the vector ALU (thread = column x 4 channels), scaled by the clip's
+//               2^-a, split, 8-byte stores; the mask rows from the bit image through a 256-entry LUT (byte -> eight f16 0/1).
+// LDS: a ring of 10 mask rows (rows 4s-1 .. 4s+4 are read while 4s+5 .. 4s+8 are written), two halves of four a1 rows with zero
+// halo columns, two log-mel tiles, the LUT.  One workgroup barrier per step (20 per clip).
+// Output: one partial [64][32][9] + [64] per workgroup (the layout of conv_wgrad_kernel) -> reduce_partials_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHRows = 4, kHSteps = kTH / kHRows, kHGRing = 10;
+struct WgH {
+    static constexpr int CIN = 32, COUT = 64;
+    static constexpr int kARec = CIN * 4 + 16, kGRec = COUT * 2 + 16;     // 144, 144 bytes
+    static constexpr int kARow = 34 * kARec, kGRow = 32 * kGRec;
+    static constexpr int kOffA = kHGRing * kGRow;
+    static constexpr int kOffMel = kOffA + 2 * kHRows * kARow;
+    static constexpr int kOffLut = kOffMel + 2 * kTMelFloats * 4;
+    static constexpr int kLds = kOffLut + 256 * 16;
+    static constexpr int kPartial = COUT * CIN * 9 + COUT;
+};
+static_assert(WgH::kLds <= 160 * 1024 && WgH::kOffA % 16 == 0 && WgH::kOffMel % 16 == 0 && WgH::kOffLut % 16 == 0, "LDS map");
+
+__global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __restrict__ mel, const uint8_t* __restrict__ maskbits,
+                                                               const float* __restrict__ gp, int n, int width,
+                                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               float* __restrict__ partial) {
+    using L = WgH;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* gring = ldsb;
+    char* aring = ldsb + L::kOffA;
+    float* meltile = reinterpret_cast<float*>(ldsb + L::kOffMel);
+    u32x4* lut = reinterpret_cast<u32x4*>(ldsb + L::kOffLut);
+    __shared__ uint32_t melmax[2], w1l1, b1max;
+    __shared__ float clip_par[2][2];                           // per clip parity: 2^-a, 2^a
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 8;
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int total = my_clips * kHSteps;
+
+    for (int i = tid; i < L::kLds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;    // halo columns / dead columns stay zero
+    if (tid == 0) { melmax[0] = 0u; melmax[1] = 0u; w1l1 = 0u; b1max = 0u; }
+    __syncthreads();
+    if (tid < 256) {
+        u32x4 m;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) m[d] = ((tid >> (2 * d)) & 1 ? 0x3c00u : 0u) | ((tid >> (2 * d + 1)) & 1 ? 0x3c000000u : 0u);
+        lut[tid] = m;
+    }
+    // the bound max_c sum |w1[c]|, max |b1| behind the activation exponent
+    if (tid < 32) {
+        float l1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) l1 += __builtin_fabsf(w1[tid * 9 + t]);
+        atomicMax(&w1l1, __float_as_uint(l1));
+        atomicMax(&b1max, __float_as_uint(__builtin_fabsf(b1[tid])));
+    }
+    auto load_mel = [&](int k, int t0, int nt) {               // clip k's tile, by threads t0 .. t0 + nt - 1
+        const float* src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kTH * width;
+        float* melt = meltile + (k & 1) * kTMelFloats;
+        float mx = 0.f;
+        for (int i = tid - t0; i < kTH * width; i += nt) {
+            const int y = i / width, xx = i - y * width;
+            const float v = src[i];
+            melt[(y + 1) * kTMelRS + xx + 1] = v;
+            mx = fmaxf(mx, __builtin_fabsf(v));
+        }
+        atomicMax(&melmax[k & 1], __float_as_uint(mx));
+    };
+    auto set_clip_par = [&](int k) {                           // one thread, after the tile's barrier
+        const float bound = fmaf(__uint_as_float(melmax[k & 1]), __uint_as_float(w1l1), __uint_as_float(b1max));
+        const int a = clampi_h(exp_of_h(bound) - 13, -100, 100);
+        clip_par[k & 1][0] = pow2i_h(-a);
+        clip_par[k & 1][1] = pow2i_h(a);
+    };
+    load_mel(0, 0, 768);
+    __syncthreads();
+    if (tid == 0) set_clip_par(0);
+    __syncthreads();
+
+    if (!consumer) {
+    // ================================================= producers =================================================
+    // conv1 weights of this producer thread (column x, channels 4 cg .. 4 cg + 3)
+    const int ptid = tid - 512;
+    const int x = ptid & 31, cg = (ptid >> 5) & 7;
+    float w1r[4][9], b1r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w1r[u][t] = w1[(4 * cg + u) * 9 + t];
+        b1r[u] = b1[4 * cg + u];
+    }
+    const int mcol = ptid >> 3, mcg = ptid & 7;                  // mask role: column, byte (8 channels) of the position's 64 bits
+    auto produce = [&](int gs) {
+        const int k = gs / kHSteps, s = gs - k * kHSteps;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        // mask rows of this step: 0 .. 4 for the clip's first step, else 4s+1 .. 4s+4 (rows beyond 79 do not exist)
+        const int g0 = s == 0 ? 0 : 4 * s + 1, g1 = 4 * s + 4 < kTH ? 4 * s + 4 : kTH - 1;
+        uint8_t mb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int g = g0 + i;
+            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mcol) * 8 + mcg] : uint8_t(0);
+        }
+        // a1 rows 4s .. 4s+3 -> half gs & 1 of the a ring
+        const float* melt = meltile + (k & 1) * kTMelFloats;
+        const float sc = clip_par[k & 1][0];
+        char* arow = aring + ((gs & 1) * kHRows) * L::kARow + (x + 1) * L::kARec + cg * 8;
+        const bool col_ok = x < width;
+#pragma unroll
+        for (int i = 0; i < kHRows; ++i) {
+            const float* mp = melt + (kHRows * s + i) * kTMelRS + x;
+            const float m00 = mp[0], m01 = mp[1], m02 = mp[2], m10 = mp[kTMelRS], m11 = mp[kTMelRS + 1], m12 = mp[kTMelRS + 2],
+                        m20 = mp[2 * kTMelRS], m21 = mp[2 * kTMelRS + 1], m22 = mp[2 * kTMelRS + 2];
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float z = b1r[u];
+                z = fmaf(w1r[u][0], m00, z); z = fmaf(w1r[u][1], m01, z); z = fmaf(w1r[u][2], m02, z);
+                z = fmaf(w1r[u][3], m10, z); z = fmaf(w1r[u][4], m11, z); z = fmaf(w1r[u][5], m12, z);
+                z = fmaf(w1r[u][6], m20, z); z = fmaf(w1r[u][7], m21, z); z = fmaf(w1r[u][8], m22, z);
+                v[u] = (col_ok && z > 0.f) ? z * sc : 0.f;
+            }
+            u32x2 hi, lo;
+            uint32_t h0, l0, h1, l1;
+            split2_h(v[0], v[1], h0, l0);
+            split2_h(v[2], v[3], h1, l1);
+            hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+            *reinterpret_cast<u32x2*>(arow + i * L::kARow) = hi;
+            *reinterpret_cast<u32x2*>(arow + i * L::kARow + L::CIN * 2) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int g = g0 + i;
+            if (g <= g1) {
+                const int slot = (k * kTH + g) % kHGRing;
+                *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + mcol * L::kGRec + mcg * 16) = lut[mb[i]];
+            }
+        }
+        // the next clip's log-mel tile and exponent, well ahead of its first step (barriers separate the three stages)
+        if (k + 1 < my_clips) {
+            if (s == 4 && ptid == 0) melmax[(k + 1) & 1] = 0u;
+            if (s == 8) load_mel(k + 1, 512, 256);
+            if (s == 12 && ptid == 0) set_clip_par(k + 1);
+        }
+    };
+
+    if (total > 0) produce(0);
+    __syncthreads();
+    for (int gs = 0; gs < total; ++gs) {
+        if (gs + 1 < total) produce(gs + 1);
+        __syncthreads();
+    }
+    } else {
+    // ================================================= consumers =================================================
+    const int ct = wave & 3, it = (wave >> 2) & 1;
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, ln = lane & 15;
+    // transposed-read bases: row = column 8 grp + 2 q of the image row (+1 for the second read), 16-bit columns 4p .. 4p+3 of the tile
+    const char* abase = gring + (8 * grp + 2 * q) * L::kGRec + (16 * ct + 4 * p) * 2;
+    const char* bbase = aring + (8 * grp + 2 * q) * L::kARec + (16 * it + 4 * p) * 2;
+    f32x4 S[9], dW[9], cnt, dbv;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { S[t][j] = 0.f; dW[t][j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cnt[j] = 0.f; dbv[j] = 0.f; }
+    half8 a_prev, a_cur, a_next, ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a_prev[j] = 0; a_cur[j] = 0; a_next[j] = 0; ones[j] = static_cast<_Float16>(1.0f); }
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_a = [&](int k, int g) -> half8 {
+        const char* r = abase + ((k * kTH + g) % kHGRing) * L::kGRow;
+        return cat8(lds_tr16(r), lds_tr16(r + L::kGRec));
+    };
+    auto consume = [&](int gs) {
+        const int k = gs / kHSteps, s = gs - k * kHSteps;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        if (s == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a_prev[j] = 0;
+            a_cur = load_a(k, 0);
+            g4 = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 16 * ct + 4 * grp);
+        }
+#pragma unroll
+        for (int i = 0; i < kHRows; ++i) {
+            const int r = kHRows * s + i;
+            if (r + 1 < kTH) a_next = load_a(k, r + 1);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a_next[j] = 0;
+            }
+            const char* br = bbase + ((gs & 1) * kHRows + i) * L::kARow;
+            half8 bh[3], bl[3];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const char* b0 = br + dx * L::kARec;
+                bh[dx] = cat8(lds_tr16(b0), lds_tr16(b0 + L::kARec));
+                bl[dx] = cat8(lds_tr16(b0 + L::CIN * 2), lds_tr16(b0 + L::kARec + L::CIN * 2));
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const half8 ay = dy == 0 ? a_next : (dy == 1 ? a_cur : a_prev);       // mask row r - dy + 1
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    S[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay, bh[dx], S[dy * 3 + dx], 0, 0, 0);
+                    S[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay, bl[dx], S[dy * 3 + dx], 0, 0, 0);
+                }
+            }
+            cnt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, ones, cnt, 0, 0, 0);  // positions with mask 1, per channel
+            a_prev = a_cur;
+            a_cur = a_next;
+        }
+        if (s == kHSteps - 1) {
+            // dW += gp[b, co] * (2^a S): D register j <-> co = 16 ct + 4 grp + j, lane & 15 <-> ci
+            const float up = clip_par[k & 1][1];
+            const float gj[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dW[t][j] = fmaf(gj[j], S[t][j] * up, dW[t][j]); S[t][j] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dbv[j] = fmaf(gj[j], cnt[j], dbv[j]); cnt[j] = 0.f; }
+        }
+    };
+
+    __syncthreads();
+    for (int gs = 0; gs < total; ++gs) {
+        consume(gs);
+        __syncthreads();
+    }
+    {
+        float* outp = partial + int64_t(blockIdx.x) * L::kPartial;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) outp[((16 * ct + 4 * grp + j) * L::CIN + 16 * it + ln) * 9 + t] = dW[t][j];
+        if (it == 0 && ln == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) outp[L::COUT * L::CIN * 9 + 16 * ct + 4 * grp + j] = dbv[j];
+        }
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int train_h_opt_in() {
+    static bool done[64] = {};
+    int dev = 0;
+    WW_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
+    if (done[dev]) return WW_OK;
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WgH::kLds));
+    done[dev] = true;
+    return WW_OK;
+}
+
+int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st) {
+    hipLaunchKernelGGL(relu_mask_bits_kernel, dim3(unsigned(n * kTH)), dim3(C), 0, st, act, C, bits);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* w1, const float* b1,
+                         float* partial, int grid, hipStream_t st) {
+    if (int rc = train_h_opt_in()) return rc;
+    hipLaunchKernelGGL(conv2_wgrad_h_kernel, dim3(grid), dim3(768), WgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), gp, int(n),
+                       width, w1, b1, partial);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+}  // namespace ww

@@ -352,6 +352,21 @@ def get_logmel_math() -> str:
     return {v: k for k, v in LOGMEL_MATH.items()}[nat.lib.ww_get_logmel_math()]
 
 
+TRAIN_MATH = {"f32": 0, "f16x3": 1}
+
+
+def set_train_math(mode: str) -> None:
+    """Arithmetic of the training step's conv kernels, process-wide: 'f16x3' (default: split precision on the f16 matrix
+    instructions where a kernel exists -- SimpleWakewordModel's conv2 backward) or 'f32' (exact fp32 matrix instructions)."""
+    if mode not in TRAIN_MATH:
+        raise ValueError(f"train math {mode!r}: expected one of {sorted(TRAIN_MATH)}")
+    nat.check(nat.lib.ww_set_train_math(TRAIN_MATH[mode]))
+
+
+def get_train_math() -> str:
+    return {v: k for k, v in TRAIN_MATH.items()}[nat.lib.ww_get_train_math()]
+
+
 def init() -> None:
     """Upload the front-end tables for the current device (needed before hipGraph capture)."""
     nat.check(nat.lib.ww_init())
