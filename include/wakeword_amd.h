@@ -273,11 +273,15 @@ WW_API int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width,
 /* Diagnostic: the dropout factors (0 or 1 / (1 - p)) the last forward on this workspace applied to the layer-0 output and to
  * fc's input, [n][256] each -- lets a test replay the step in another framework with the same masks. */
 WW_API int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, float* mask0_dev, float* mask1_dev, ww_stream_t stream);
+/* Diagnostic: the packed image (ww_packed_weights_floats(2) floats) that the last WW_TRAIN_MATH_F16X3 forward of the 2-conv model wrote on
+ * the device from the live parameters -- its conv1 / conv2-Winograd / range entries equal ww_pack_weights_host's bit for bit; the rest is 0. */
+WW_API int ww_train_packed_image(const void* workspace_dev, int64_t n, int32_t n_conv, float* img_dev, ww_stream_t stream);
 /* Arithmetic of the training step's convolution kernels, process-wide (the head is always exact fp32):
  *   WW_TRAIN_MATH_F32    exact fp32 matrix instructions throughout (v_mfma_f32_32x32x2_f32)
  *   WW_TRAIN_MATH_F16X3  (default) split precision on the f16 matrix instructions wherever a kernel exists (SimpleWakewordModel's conv2
- *                        backward: one operand is the 0/1 ReLU mask, exact in f16; the other is carried as two f16 halves); the
- *                        remaining kernels run as under F32.  Gradients agree with F32 to the 2^-22 of the split. */
+ *                        forward = the inference kernel with the ReLU mask as a second output, conv2 backward: one operand is the
+ *                        0/1 mask, exact in f16; the other is carried as two f16 halves); the remaining kernels run as under F32.
+ *                        Gradients agree with F32 to the 2^-22 of the split.  A step's forward and backward must run under the same mode. */
 #define WW_TRAIN_MATH_F32 0
 #define WW_TRAIN_MATH_F16X3 1
 WW_API int ww_set_train_math(int mode);

@@ -345,6 +345,11 @@ int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, float* 
     return train_masks(workspace_dev, n, n_conv, mask0_dev, mask1_dev, static_cast<hipStream_t>(stream));
 }
 
+int ww_train_packed_image(const void* workspace_dev, int64_t n, int32_t n_conv, float* img_dev, ww_stream_t stream) {
+    if (!workspace_dev || !img_dev || n < 1 || (n_conv != 2 && n_conv != 3)) return fail(WW_EINVAL, "ww_train_packed_image: bad arguments");
+    return train_packed_image(workspace_dev, n, n_conv, img_dev, static_cast<hipStream_t>(stream));
+}
+
 int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params, const float* dlogits_dev,
                           void* workspace_dev, const ww_train_grads* grads, ww_stream_t stream) {
     if (int rc = check_train(mel_dev, n, width, params, workspace_dev)) return rc;

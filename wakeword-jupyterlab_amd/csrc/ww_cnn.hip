@@ -25,11 +25,10 @@
 #include <cstdlib>
 #include <mutex>
 
+#include "ww_conv1.h"
 #include "ww_internal.h"
 
 namespace ww {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kH = WW_N_MELS;      // image rows
 constexpr int kW = 32;             // image columns = lanes of an M-tile
@@ -199,12 +198,6 @@ __global__ __launch_bounds__(256, 2) void cnn2_kernel(const float* __restrict__ 
 // the fp32 accumulator.  Weights are pre-scaled by 2^S on the host (both halves normal f16); the accumulator is
 // descaled by 2^-S.
 // ------------------------------------------------------------------------------------------------
-using half8 = __attribute__((ext_vector_type(8))) _Float16;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-
-// 2*relu(v) = v + |v| : one VALU op, exact, NaN-propagating (the factor 2 is folded into the pool scale)
-__device__ __forceinline__ float relu2(float v) { return v + __builtin_fabsf(v); }
-
 // ------------------------------------------------------------------------------------------------
 // Split-precision conv1+conv2 kernel (v_mfma_f32_16x16x32_f16): 12 waves per workgroup (one per CU, 3 waves per SIMD,
 // <= 168 VGPRs):
@@ -214,92 +207,10 @@ __device__ __forceinline__ float relu2(float v) { return v + __builtin_fabsf(v);
 // Position record = 160 bytes ([32 ci hi][32 ci lo][32 B pad]): conflict-free for the 16x16x32 A-fragment reads
 // (lane = (position i, channel quarter kq) reads 16 B at position*160 + kq*16).
 // ------------------------------------------------------------------------------------------------
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kPos16 = 160;
 constexpr int kH16Row = kRS * kPos16;
 constexpr int kH16Act = kARows * kH16Row;                   // 54,400 B per buffer
 constexpr int kC2h16Lds = 2 * kH16Act + 4 * ((kH + 2) * 36) * 2 + 8 * 16 * 4;
-
-// conv1 on the matrix cores for the producers: one v_mfma_f32_32x32x16_f16 triple per image row,
-//   D[ci][x] = sum_k W1'[ci][k] * P'[k][x],  k = 3*dy + dx (9 taps; the other 7 of the 16 are zero), split precision as conv2.
-// The log-mel tile is kept as two f16 planes (hi, lo) so the patch operand needs no conversions.  The result lands
-// with the column on the lane and 16 channels in registers: descale, 2*relu, split, 8-byte stores
-// into the position records.  The bias enters as the MFMA's C operand (16 VGPRs per producer lane, rebuilt per clip).
-//
-// Dynamic range (so that the split precision holds for ANY finite weights and inputs, not only log-mel in [-80, 0] dB):
-//   weights   conv1: one power-of-two scale 2^S1 for the tensor (a wave-uniform descale); conv2 / conv3 / LSTM: every
-//             output channel has its own (a per-lane constant of the D layout) -- host, ww_tables.cpp;
-//   inputs    P' = x * 2^-e with ONE exponent e per clip, chosen from the clip's max |x| so that max |P'| is in [2^14, 2^15);
-//   outputs   the tile holds 2 relu(conv1) * 2^-a with one exponent a per clip chosen from the bound
-//             max|x| * max_c sum_k |w1[c][k]| + max |b1|, so that it stays below 2^15 (f16 overflows at 65504) and
-//             small activations keep both halves normal;  conv2's descale carries 2^a.
-// Powers of two commute with fp32 rounding, so for log-mel inputs the result is what the unscaled arithmetic gives.
-constexpr int kMelHRS = 36;                              // f16 plane row stride (columns -1..34)
-constexpr int kMelHPlane = (kH + 2) * kMelHRS;           // halfs per plane
-// One row of conv1 on the matrix cores, split into its three stages so that a producer can run the stages of its
-// (up to three) rows side by side: the LDS, MFMA and VALU latencies of one row hide under the other rows' work.
-struct Conv1Row {
-    half8 ph, pl;       // patch operand B[k = 8h + j][x], hi and lo halves
-    f32x16 acc;
-};
-
-// The per-clip constants of a producer lane: the accumulator of channel c = 16h + j starts at binit[j] = b1[c] * 2^(S1 - e)
-// (the bias in the accumulator's scale) and the finished row is multiplied by sc = 2^(e - a - S1) (wave-uniform).
-struct Conv1Scale { f32x16 binit; float sc; };
-
-// floor(log2 |v|) of a normal float (-127 for zero / subnormals, 128 for inf / NaN)
-__device__ __forceinline__ int exp_of(float v) { return int((__float_as_uint(v) >> 23) & 0xffu) - 127; }
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ float pow2i(int e) { return __uint_as_float(uint32_t(127 + e) << 23); }   // -126 <= e <= 127
-
-// Patch operand of a row: lane (x, h) needs B[k = 8h + j][x], j = 0..7 -- taps 0..7 for the lower half-wave; tap 8 and
-// seven zeros for the upper one.  Columns 34 and 35 of every plane row are zero, so the upper half-wave differs from the
-// lower one only in its ADDRESSES: eight per-lane offsets, computed once, replace 32 selects per row.  (ds_read_u16_d16
-// pairs would also save the packing, but with SRAM ECC on a d16 load clears the other half of its register.)
-struct GatherLanes { int o[8]; };      // offsets in halfs relative to the first plane row of the patch, column 0
-
-__device__ __forceinline__ GatherLanes gather_lanes(int x, int h) {
-    GatherLanes g;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int lower = (j / 3) * kMelHRS + j % 3 + x;                             // tile coords: row y+dy, col x+dx
-        const int upper = j == 0 ? 2 * kMelHRS + 2 + x : 34 + (j & 1);
-        g.o[j] = h ? upper : lower;
-    }
-    return g;
-}
-
-__device__ __forceinline__ void conv1_row_gather(Conv1Row& r, const _Float16* __restrict__ mh, const GatherLanes& gl, int y) {
-    const _Float16* __restrict__ row = mh + y * kMelHRS;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r.ph[j] = row[gl.o[j]];
-        r.pl[j] = row[gl.o[j] + kMelHPlane];             // the lo plane follows the hi plane
-    }
-}
-
-__device__ __forceinline__ void conv1_row_mfma(Conv1Row& r, half8 a1h, half8 a1l, const Conv1Scale& cs) {
-    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, r.ph, cs.binit, 0, 0, 0);
-    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, r.pl, r.acc, 0, 0, 0);
-    r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, r.ph, r.acc, 0, 0, 0);
-}
-
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-// x ~= hi + lo for two values at once: v_cvt_pk_f16_f32, two v_fma_mix_f32, v_cvt_pk_f16_f32
-// (2 VALU instructions per value instead of 6 for the scalar form; same round-to-nearest result)
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const float2_t v = {a, b};
-    const half2_t h = __builtin_convertvector(v, half2_t);
-    // a - float(hi) as one mixed-precision fma per value (v_fma_mix_f32 reads the f16 half directly, exact like the subtraction):
-    // 4 instructions per pair instead of 5 with a half-rate packed subtract (bit-identical, -3 % on the conv kernel)
-    const float2_t r = {__builtin_fmaf(static_cast<float>(h[0]), -1.0f, a), __builtin_fmaf(static_cast<float>(h[1]), -1.0f, b)};
-    const half2_t l = __builtin_convertvector(r, half2_t);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-
 
 // D: lane&31 = column x; the weight rows are permuted on the host so that register j holds channel 16*h + j:
 // descale, 2*relu, hi/lo split, and the lane's 16 contiguous channels go out as two 16-byte stores per half.
@@ -771,15 +682,18 @@ constexpr int kWPerGroup = kWTileRows / 2;          // 20 tile rows per consumer
 constexpr int kCWLds = kWNB * kWBuf + 4 * kMelHPlane * 2 + 2 * 8 * 16 * 4;
 static_assert(kWTileRows % 4 == 0, "four producers with equal shares");
 
-// POOL: out = pooled [n][64].   !POOL (3-conv model): out = relu(conv2) as float32 [n][80 rows][32 columns][64 channels] (zero beyond
-// `width`) for cnn3w_kernel, and apow2[clip] = 2^a2, the exponent that kernel gives its transformed conv3 inputs.
-template <bool POOL>
+// OUT 1 (POOL): out = pooled [n][64].   OUT 0 (3-conv model): out = relu(conv2) as float32 [n][80 rows][32 columns][64 channels] (zero
+// beyond `width`) for cnn3w_kernel, and apow2[clip] = 2^a2, the exponent that kernel gives its transformed conv3 inputs.
+// OUT 2 (training forward of the 2-conv model): pooled as under OUT 1, plus bits[n][80][32] = 64 bits per position,
+// bit c = [relu(conv2)[c] > 0] (as 4 x uint16, one per N-tile): all the backward pass needs of relu(conv2) (ww_train_h.hip).
+template <int OUT>
 __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__ mel, int n, int width,
                                                        const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
                                                        const float* __restrict__ b1,
                                                        const u32x4* __restrict__ wH, const float* __restrict__ hs,
                                                        const float* __restrict__ b2, const float* __restrict__ rng,
-                                                       float* __restrict__ out, float* __restrict__ apow2) {
+                                                       float* __restrict__ out, float* __restrict__ apow2, uint16_t* __restrict__ bits) {
+    constexpr bool POOL = OUT != 0, BITS = OUT == 2;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* act0 = ldsb;
     _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + kWNB * kWBuf);      // 2 clips x (hi plane, lo plane) of [82][36] f16
@@ -998,7 +912,8 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             // output transform + bias + 2*relu + pool (D: lane & 15 = channel, register j <-> column 16 c + 4 kq + j)
             const int trow = kWPerProd * (2 * grp + (sq & 1)) + (sq >> 1);      // the tile row this step holds (producer 2 grp + (sq & 1), its i-th)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c) {
+                unsigned long long live0[4], live1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float m12 = acc[1][c][j] + acc[2][c][j], m1m2 = acc[1][c][j] - acc[2][c][j];
@@ -1013,7 +928,22 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                         o[0] = col_live ? 0.5f * v0 : 0.f;
                         o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
                     }
+                    if constexpr (BITS) {       // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
+                        live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
+                        live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
+                    }
                 }
+                if constexpr (BITS) {           // lane (kq, pi < 4) stores the 16 channel bits of column 16 c + 4 kq + pi, both rows
+                    const unsigned long long s0 = pi == 0 ? live0[0] : (pi == 1 ? live0[1] : (pi == 2 ? live0[2] : live0[3]));
+                    const unsigned long long s1 = pi == 0 ? live1[0] : (pi == 1 ? live1[1] : (pi == 2 ? live1[2] : live1[3]));
+                    if (pi < 4) {
+                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                        uint16_t* o = bits + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + pi) * 4 + nt;
+                        o[0] = uint16_t(s0 >> (16 * kq));
+                        o[kW * 4] = uint16_t(s1 >> (16 * kq));
+                    }
+                }
+            }
             if (POOL && sq == kWPerGroup - 1) {               // this wave's last tile row of the clip
                 float p2 = pool + __shfl_xor(pool, 16);
                 p2 += __shfl_xor(p2, 32);
@@ -1405,6 +1335,7 @@ static int opt_in_lds() {
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2h16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC2h16Lds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1412,6 +1343,21 @@ static int opt_in_lds() {
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                int(sizeof(float) * kC3LdsFloats)));
     done[dev] = true;
+    return WW_OK;
+}
+
+// training forward of the 2-conv model in split precision (ww_train.hip): the inference kernel with the ReLU mask as a second output.
+// `packed`: a packed image whose conv1 / conv2-Winograd / range entries were written on the device from the live parameters.
+int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    const PackedLayout L = packed_layout(2);
+    if (int rc = opt_in_lds()) return rc;
+    const int cus = device_cu_count();
+    hipLaunchKernelGGL(cnn2w_kernel<2>, dim3(int(n < cus ? n : cus)), dim3(768), kCWLds, stream, mel, int(n), width,
+                       reinterpret_cast<const u32x4*>(packed + L.conv1_h), packed + L.conv1_hs, packed + L.conv1_b,
+                       reinterpret_cast<const u32x4*>(packed + L.conv2_hw), packed + L.conv2_hws, packed + L.conv2_b, packed + L.range, pooled,
+                       static_cast<float*>(nullptr), reinterpret_cast<uint16_t*>(bits));
+    WW_HIP(hipGetLastError());
     return WW_OK;
 }
 
@@ -1454,14 +1400,14 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
             if (n_conv == 2) {
                 hipLaunchKernelGGL(cnn2w_kernel<true>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
                                    packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
-                                   packed + L.range, pooled, static_cast<float*>(nullptr));
+                                   packed + L.range, pooled, static_cast<float*>(nullptr), static_cast<uint16_t*>(nullptr));
                 WW_HIP(hipGetLastError());
                 return WW_OK;
             }
             float* apw = reinterpret_cast<float*>(static_cast<char*>(scratch) + mid_bytes(n));
             hipLaunchKernelGGL(cnn2w_kernel<false>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
                                packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
-                               packed + L.range, static_cast<float*>(scratch), apw);
+                               packed + L.range, static_cast<float*>(scratch), apw, static_cast<uint16_t*>(nullptr));
             WW_HIP(hipGetLastError());
             hipLaunchKernelGGL(cnn3w_kernel, dim3(grid1), dim3(512), kC3wLds, stream, static_cast<const float*>(scratch),
                                static_cast<const float*>(apw), int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_hw),

@@ -135,11 +135,14 @@ int64_t train_workspace_bytes(int64_t n, int n_conv);
 int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
                   float* logits, hipStream_t st);
 int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, float* mask1, hipStream_t st);
+int train_packed_image(const void* workspace, int64_t n, int n_conv, float* img, hipStream_t st);
 int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
                    const ww_train_grads* g, hipStream_t st);
 
 int train_math_mode();   // 0 exact fp32, 1 split-precision conv backward where a kernel exists (ww_train_h.hip)
 int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st);
+int launch_pack_conv_h_dev(const float* w1, const float* b1, const float* w2, const float* b2, float* img, hipStream_t st);
+int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, hipStream_t stream);
 int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* w1, const float* b1,
                          float* partial, int grid, hipStream_t st);
 

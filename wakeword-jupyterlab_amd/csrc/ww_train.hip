@@ -272,7 +272,7 @@ struct DgradCfg {
 };
 constexpr int kDgPartial = 32 * 9 + 32;
 
-template <int CIN, int COUT, bool DENSE, bool TO_CONV1>
+template <int CIN, int COUT, bool DENSE, bool TO_CONV1, bool BITS = false>
 __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dgrad_kernel(
     const float* __restrict__ mel, const float* __restrict__ iact, const float* __restrict__ oact_or_dz, const float* __restrict__ gp, int n,
     int width, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wB, float* __restrict__ out) {
@@ -316,9 +316,17 @@ __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dg
                 const int y = y0 - 1 + q;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
                 if (y >= 0 && y < kTH) {
-                    const float* src = oact_or_dz + ((int64_t(clip) * kTH + y) * COUT + lco) * kTW + lcol;
-                    a = *reinterpret_cast<const float4*>(src);
-                    b = *reinterpret_cast<const float4*>(src + 4);
+                    if constexpr (BITS) {      // the mask as bits [b][row][col][COUT bits] (split-precision forward): 1.0 where set
+                        const uint8_t* mb = reinterpret_cast<const uint8_t*>(oact_or_dz) + ((int64_t(clip) * kTH + y) * kTW + lcol) * (COUT / 8) + (lco >> 3);
+                        const int sh = lco & 7;
+                        a.x = float((mb[0] >> sh) & 1); a.y = float((mb[COUT / 8] >> sh) & 1); a.z = float((mb[2 * (COUT / 8)] >> sh) & 1);
+                        a.w = float((mb[3 * (COUT / 8)] >> sh) & 1); b.x = float((mb[4 * (COUT / 8)] >> sh) & 1); b.y = float((mb[5 * (COUT / 8)] >> sh) & 1);
+                        b.z = float((mb[6 * (COUT / 8)] >> sh) & 1); b.w = float((mb[7 * (COUT / 8)] >> sh) & 1);
+                    } else {
+                        const float* src = oact_or_dz + ((int64_t(clip) * kTH + y) * COUT + lco) * kTW + lcol;
+                        a = *reinterpret_cast<const float4*>(src);
+                        b = *reinterpret_cast<const float4*>(src + 4);
+                    }
                 }
                 float* d = gmt + (lco * R + q) * kTRS + lcol + 1;
                 if constexpr (DENSE) {
@@ -566,6 +574,7 @@ struct TrainWs {
     float *mid2, *mid3, *dz2, *pooled, *gates0, *mask0, *hd0, *gates1, *mask1, *hd1, *lstm_packed, *conv2_b_op, *conv3_b_op, *dgrad2_b_op, *dgrad3_b_op;
     float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *partial, *reduced;
     uint32_t* maskbits;                                  // [n][80][32][c_last / 32]: [relu(last conv) > 0]
+    float* wpk;                                          // 2-conv model, split precision: packed image written on the device
     int64_t total;
 };
 static int64_t a256(int64_t floats) { return (floats * 4 + 255) / 256 * 64; }      // floats, 256-byte granules
@@ -591,6 +600,7 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     w.partial = take(int64_t(kMaxGroups) * (n_conv == 3 ? kWg3Partial : kWg2Partial));      // reused by every partial-producing kernel in turn
     w.reduced = take(n_conv == 3 ? kWg3Partial : kWg2Partial);
     w.maskbits = reinterpret_cast<uint32_t*>(take(n * kTH * kTW * (c_last / 32)));
+    w.wpk = n_conv == 2 ? take(packed_layout(2).total) : nullptr;
     w.total = o * 4;
     return w;
 }
@@ -610,6 +620,7 @@ static int train_opt_in() {
     WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<32, 64, 8, true, true>), WgradCfg<32, 64, 8>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<64, 128, 4, false, false>), WgradCfg<64, 128, 4>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, false, true>), DgradCfg<32, 64>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, false, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false>), DgradCfg<64, 128>::kLdsFloats));
     done[dev] = true;
@@ -624,11 +635,29 @@ int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, floa
     return WW_OK;
 }
 
+// test / diagnostic: the packed image the last split-precision forward of the 2-conv model wrote on the device
+int train_packed_image(const void* workspace, int64_t n, int n_conv, float* img, hipStream_t st) {
+    if (n_conv != 2) return fail(WW_EUNSUPPORTED, "the device-packed image exists for the 2-conv model only");
+    TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv);
+    WW_HIP(hipMemcpyAsync(img, w.wpk, sizeof(float) * packed_layout(2).total, hipMemcpyDeviceToDevice, st));
+    return WW_OK;
+}
+
 int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
                   float* logits, hipStream_t st) {
     if (device_cu_count() > kMaxGroups) return fail(WW_EUNSUPPORTED, "more than 256 CUs: the workspace is sized for 256 partials");
     const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
     TrainWs w = carve_train(workspace, n, nc);
+    if (train_math_mode() == WW_TRAIN_MATH_F16X3 && nc == 2) {
+        // split precision: the inference kernel (conv2 as 1-D Winograd on the f16 matrix cores) with the ReLU mask as a second output;
+        // relu(conv2) itself is never stored.  The backward pass must run under the same arithmetic (it reads the mask bits).
+        WW_HIP(hipMemsetAsync(w.wpk, 0, sizeof(float) * packed_layout(2).total, st));
+        if (int rc = launch_pack_conv_h_dev(p->conv_weight[0], p->conv_bias[0], p->conv_weight[1], p->conv_bias[1], w.wpk, st)) return rc;
+        if (int rc = launch_cnn2w_pool_bits(mel, n, width, w.wpk, w.pooled, w.maskbits, st)) return rc;
+        return launch_lstm_fc_train(w.pooled, n, c_last, p->lstm_weight_ih[0], p->lstm_bias_ih[0], p->lstm_bias_hh[0], p->lstm_weight_ih[1],
+                                    p->lstm_bias_ih[1], p->lstm_bias_hh[1], p->fc_weight, p->fc_bias, w.lstm_packed, w.gates0, w.mask0, w.hd0,
+                                    w.gates1, w.mask1, w.hd1, p_lstm, p_fc, seed, logits, st);
+    }
     hipLaunchKernelGGL(pack_conv_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], 64, 32, w.conv2_b_op);
     WW_HIP(hipGetLastError());
     if (int rc = launch_cnn2_f32_mid(mel, n, width, p->conv_weight[0], p->conv_bias[0], w.conv2_b_op, p->conv_bias[1], w.mid2, st)) return rc;
@@ -697,7 +726,6 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, true, true>), dim3(grid), dim3(512), kWg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.partial);
     else if (split) {
-        if (int rc = launch_relu_mask_bits(w.mid2, n, 64, w.maskbits, st)) return rc;
         if (int rc = launch_conv2_wgrad_h(mel, w.maskbits, w.gp, n, width, w1, b1, w.partial, grid, st)) return rc;
     } else
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, false, true>), dim3(grid), dim3(512), kWg2Lds, st,
@@ -707,6 +735,10 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     if (nc == 3)
         hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, true, true>), dim3(grid), dim3(256), kDg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.dgrad2_b_op, w.partial);
+    else if (split)
+        hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, false, true, true>), dim3(grid), dim3(256), kDg2Lds, st,
+                           mel, static_cast<const float*>(nullptr), reinterpret_cast<const float*>(w.maskbits), w.gp, N, width, w1, b1,
+                           w.dgrad2_b_op, w.partial);
     else
         hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, false, true>), dim3(grid), dim3(256), kDg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.mid2, w.gp, N, width, w1, b1, w.dgrad2_b_op, w.partial);

@@ -51,6 +51,128 @@ __device__ __forceinline__ half8 cat8(fp16x4 a, fp16x4 b) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The split-precision images of conv1 and conv2 (1-D Winograd) written ON THE DEVICE from the live torch-layout parameters: the
+// weights change with every optimiser step, so the host packers of ww_tables.cpp (pack_conv1_f16x3, pack_conv_wino_f16x3, the
+// range bounds) are restated here value for value (same double arithmetic, same exponents, same operand order) -- a test
+// compares the two images bit for bit.  img: a packed image (packed_layout(2)); only the entries named below are written.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int scale_exp_dev(float wmax) {
+    if (!(wmax > 0.f) || !__builtin_isfinite(wmax)) return 0;
+    int e = 0;
+    (void)frexpf(wmax, &e);                     // wmax = f * 2^e, f in [0.5, 1)
+    const int S = 13 - e;                       // wmax * 2^S in [2^12, 2^13)
+    return S > 120 ? 120 : (S < -100 ? -100 : S);
+}
+__device__ __forceinline__ void split_f16_dev(double v, uint16_t& hb, uint16_t& lb) {
+    const float vf = float(v);
+    const _Float16 hi = static_cast<_Float16>(vf);
+    const _Float16 lo = static_cast<_Float16>(vf - static_cast<float>(hi));
+    hb = __builtin_bit_cast(uint16_t, hi);
+    lb = __builtin_bit_cast(uint16_t, lo);
+}
+struct PackOffsets { int64_t conv1_h, conv1_hs, conv1_b, conv2_hw, conv2_hws, conv2_b, range; };
+
+// one workgroup of 256 threads: conv1 operand + scale, both biases, range[0], [1], [3]; range[2] = 0 for the conv2 kernel's atomic max
+__global__ __launch_bounds__(256) void pack_conv1_h_dev_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               const float* __restrict__ b2, float* __restrict__ img, PackOffsets o) {
+    __shared__ float red[256];
+    __shared__ double redd[32];
+    const int tid = threadIdx.x;
+    float m = 0.f;
+    for (int i = tid; i < 32 * 9; i += 256) m = fmaxf(m, __builtin_fabsf(w1[i]));
+    red[tid] = m;
+    if (tid < 32) {
+        double s = 0.0;
+        for (int t = 0; t < 9; ++t) s += fabs(double(w1[tid * 9 + t]));
+        redd[tid] = s;
+    }
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    const int S = scale_exp_dev(red[0]);
+    __syncthreads();
+    if (tid < 4) img[o.conv1_hs + tid] = tid == 0 ? ldexpf(1.0f, -S) : 0.f;
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(img + o.conv1_h);
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int lane = i >> 3, j = i & 7;
+        const int mrow = lane & 31, k = 8 * (lane >> 5) + j;
+        const int mch = (mrow & 3) + 4 * (mrow >> 3) + 16 * ((mrow >> 2) & 1);
+        uint16_t hb, lb;
+        split_f16_dev(k < 9 ? ldexp(double(w1[mch * 9 + k]), S) : 0.0, hb, lb);
+        o16[lane * 8 + j] = hb;
+        o16[64 * 8 + lane * 8 + j] = lb;
+    }
+    if (tid < 32) img[o.conv1_b + tid] = b1[tid];
+    if (tid < 64) img[o.conv2_b + tid] = b2[tid];
+    // range: |conv1 out| <= max|in| * range[0] + range[1]; the same for conv2 with [2], [3]
+    red[tid] = tid < 32 ? __builtin_fabsf(b1[tid]) : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        double best = 0.0;
+        float bm = 0.f;
+        for (int c = 0; c < 32; ++c) { best = fmax(best, redd[c]); bm = fmaxf(bm, red[c]); }
+        img[o.range + 0] = float(best * (1.0 + 1e-6));
+        img[o.range + 1] = bm;
+        float b2m = 0.f;
+        for (int c = 0; c < 64; ++c) b2m = fmaxf(b2m, __builtin_fabsf(b2[c]));
+        img[o.range + 2] = 0.f;
+        img[o.range + 3] = b2m;
+#pragma unroll
+        for (int i = 4; i < 8; ++i) img[o.range + i] = 0.f;
+    }
+}
+
+// one workgroup of 128 threads per output channel co (thread = (ci, dx) for 96 of them): U0 = w[dy=0], U1 = (w0+w1+w2)/2,
+// U2 = (w0-w1+w2)/2, U3 = w[dy=2] in double; the channel's exponent from max |U|; operand order [nt][ks = xi*3+dx][hi,lo][lane][8]
+__global__ __launch_bounds__(128) void pack_conv2_wino_dev_kernel(const float* __restrict__ w2, float* __restrict__ img, PackOffsets o) {
+    __shared__ double red[128];
+    const int co = blockIdx.x, tid = threadIdx.x;
+    const int ci = tid / 3, dx = tid - 3 * ci;
+    double u[4] = {0., 0., 0., 0.};
+    if (tid < 96) {
+        const double w0 = w2[((co * 32 + ci) * 3 + 0) * 3 + dx], w1v = w2[((co * 32 + ci) * 3 + 1) * 3 + dx], w2v = w2[((co * 32 + ci) * 3 + 2) * 3 + dx];
+        u[0] = w0; u[1] = 0.5 * (w0 + w1v + w2v); u[2] = 0.5 * (w0 - w1v + w2v); u[3] = w2v;
+    }
+    red[tid] = fmax(fmax(fabs(u[0]), fabs(u[1])), fmax(fabs(u[2]), fabs(u[3])));
+    __syncthreads();
+    for (int off = 64; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    const int S = scale_exp_dev(float(red[0]) * 1.0000001f);
+    if (tid == 0) {                              // the row's l1 norm summed in the host's order by one thread
+        img[o.conv2_hws + co] = ldexpf(1.0f, -S);
+        double s = 0.0;
+        for (int i = 0; i < 32 * 9; ++i) s += fabs(double(w2[co * 288 + i]));
+        atomicMax(reinterpret_cast<unsigned int*>(img + o.range + 2), __float_as_uint(float(s * (1.0 + 1e-6))));
+    }
+    if (tid < 96) {
+        uint16_t* o16 = reinterpret_cast<uint16_t*>(img + o.conv2_hw);
+        const int nt = co >> 4, lane = (co & 15) + 16 * ((ci & 31) >> 3), j = ci & 7;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const int ks = xi * 3 + dx;
+            uint16_t hb, lb;
+            split_f16_dev(ldexp(u[xi], S), hb, lb);
+            const int64_t base = ((int64_t(nt) * 12 + ks) * 2) * 64 * 8;
+            o16[base + lane * 8 + j] = hb;
+            o16[base + 64 * 8 + lane * 8 + j] = lb;
+        }
+    }
+}
+
+int launch_pack_conv_h_dev(const float* w1, const float* b1, const float* w2, const float* b2, float* img, hipStream_t st) {
+    const PackedLayout L = packed_layout(2);
+    const PackOffsets o{L.conv1_h, L.conv1_hs, L.conv1_b, L.conv2_hw, L.conv2_hws, L.conv2_b, L.range};
+    hipLaunchKernelGGL(pack_conv1_h_dev_kernel, dim3(1), dim3(256), 0, st, w1, b1, b2, img, o);
+    hipLaunchKernelGGL(pack_conv2_wino_dev_kernel, dim3(64), dim3(128), 0, st, w2, img, o);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // relu(conv) [b][row][C][32 columns] floats (cnn2_kernel<false> / cnn3_kernel<STORE>) -> mask bits [b][row][32 columns][C/32 words].
 // One workgroup of C threads per (clip, row): thread = channel reads its 32 columns, one ballot per column.
 // ------------------------------------------------------------------------------------------------
@@ -235,7 +357,9 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
     if (total > 0) produce(0);
     __syncthreads();
     for (int gs = 0; gs < total; ++gs) {
+#ifndef WW_HABL_NOPROD            // timing-only ablation: consumers alone (results are garbage)
         if (gs + 1 < total) produce(gs + 1);
+#endif
         __syncthreads();
     }
     } else {
@@ -313,7 +437,9 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
 
     __syncthreads();
     for (int gs = 0; gs < total; ++gs) {
+#ifndef WW_HABL_NOCONS            // timing-only ablation: producers alone
         consume(gs);
+#endif
         __syncthreads();
     }
     {

@@ -260,6 +260,7 @@ class _TrainStep(torch.autograd.Function):
     reference never asks for one)."""
     last_workspace = None
     last_n_conv = 2
+    last_n = 0
 
     @staticmethod
     def forward(ctx, x, n_conv, p_lstm, p_fc, seed, *params):
@@ -278,7 +279,8 @@ class _TrainStep(torch.autograd.Function):
                                                    _ptr(ws), _ptr(logits), _stream()))
         ctx.save_for_backward(x, ws, *params)
         ctx.n_conv = n_conv
-        _TrainStep.last_workspace, _TrainStep.last_n_conv = ws, n_conv
+        ctx.train_math = nat.lib.ww_get_train_math()        # the backward reads what this forward left in the workspace
+        _TrainStep.last_workspace, _TrainStep.last_n_conv, _TrainStep.last_n = ws, n_conv, B
         return logits
 
     @staticmethod
@@ -299,7 +301,12 @@ class _TrainStep(torch.autograd.Function):
         tg.fc_weight, tg.fc_bias = grads[o + 8].data_ptr(), grads[o + 9].data_ptr()
         with torch.cuda.device(x.device):
             tp = _train_params_struct(params, n_conv)
-            nat.check(nat.lib.ww_train_backward_f32(_ptr(x), B, T, C.byref(tp), _ptr(dlogits), _ptr(ws), C.byref(tg), _stream()))
+            now = nat.lib.ww_get_train_math()
+            nat.check(nat.lib.ww_set_train_math(ctx.train_math))
+            try:
+                nat.check(nat.lib.ww_train_backward_f32(_ptr(x), B, T, C.byref(tp), _ptr(dlogits), _ptr(ws), C.byref(tg), _stream()))
+            finally:
+                nat.check(nat.lib.ww_set_train_math(now))
         grads[o + 3].copy_(grads[o + 2])    # d/d bias_hh == d/d bias_ih
         grads[o + 7].copy_(grads[o + 6])
         return (None, None, None, None, None, *grads)
@@ -318,6 +325,15 @@ def train_last_masks(n: int):
     with torch.cuda.device(ws.device):
         nat.check(nat.lib.ww_train_masks(_ptr(ws), n, _TrainStep.last_n_conv, _ptr(m0), _ptr(m1), _stream()))
     return m0, m1
+
+
+def train_last_packed_image() -> torch.Tensor:
+    """Diagnostic: the packed image the most recent split-precision training forward of the 2-conv model wrote on the device."""
+    ws = _TrainStep.last_workspace
+    img = torch.empty(int(nat.lib.ww_packed_weights_floats(2)), device=ws.device, dtype=torch.float32)
+    with torch.cuda.device(ws.device):
+        nat.check(nat.lib.ww_train_packed_image(_ptr(ws), _TrainStep.last_n, _TrainStep.last_n_conv, _ptr(img), _stream()))
+    return img
 
 
 CONV_MATH = {"f32": 0, "f16x3": 1, "f16x3d": 2}
