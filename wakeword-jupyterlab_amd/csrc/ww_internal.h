@@ -143,7 +143,7 @@ int train_math_mode();   // 0 exact fp32, 1 split-precision conv backward where 
 int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st);
 int launch_pack_conv_h_dev(const float* w1, const float* b1, const float* w2, const float* b2, float* img, hipStream_t st);
 int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, hipStream_t stream);
-int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* w1, const float* b1,
+int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* packed,
                          float* partial, int grid, hipStream_t st);
 
 int require_gfx950();

@@ -726,7 +726,7 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, true, true>), dim3(grid), dim3(512), kWg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.partial);
     else if (split) {
-        if (int rc = launch_conv2_wgrad_h(mel, w.maskbits, w.gp, n, width, w1, b1, w.partial, grid, st)) return rc;
+        if (int rc = launch_conv2_wgrad_h(mel, w.maskbits, w.gp, n, width, w.wpk, w.partial, grid, st)) return rc;
     } else
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, false, true>), dim3(grid), dim3(512), kWg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.mid2, w.gp, N, width, w1, b1, w.partial);

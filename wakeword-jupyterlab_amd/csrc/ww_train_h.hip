@@ -12,33 +12,17 @@
 //
 // The mask travels as BITS: maskbits[b][row][col] = COUT bits (bit c of the position's word(s) = [relu(conv)[c] > 0]), 20 KB per clip
 // instead of the 655 KB of the float activations.
+#include "ww_conv1.h"
 #include "ww_internal.h"
 
 namespace ww {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
-using half8 = __attribute__((ext_vector_type(8))) _Float16;
-using half2_t = __attribute__((ext_vector_type(2))) _Float16;
-using float2_t = __attribute__((ext_vector_type(2))) float;
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 constexpr int kTH = WW_N_MELS, kTW = 32;
-constexpr int kTMelRS = 36, kTMelFloats = (kTH + 2) * kTMelRS;   // log-mel tile with a zero halo (as in ww_train.hip)
 
-__device__ __forceinline__ int exp_of_h(float v) { return int((__float_as_uint(v) >> 23) & 0xffu) - 127; }
-__device__ __forceinline__ int clampi_h(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ float pow2i_h(int e) { return __uint_as_float(uint32_t(127 + e) << 23); }
-// x ~= hi + lo for two values at once (the forward kernels' split2)
-__device__ __forceinline__ void split2_h(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const float2_t v = {a, b};
-    const half2_t h = __builtin_convertvector(v, half2_t);
-    const float2_t r = {__builtin_fmaf(static_cast<float>(h[0]), -1.0f, a), __builtin_fmaf(static_cast<float>(h[1]), -1.0f, b)};
-    const half2_t l = __builtin_convertvector(r, half2_t);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
+
 // ds_read_b64_tr_b16: within a group of 16 lanes, lane 4q + p supplies the address of row q, 16-bit columns 4p .. 4p+3 of a 4 x 16 block;
 // lane i receives column i, row q in element q (scripts/ubench/tr_read.hip).  EXEC must be all ones.
 __device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
@@ -222,7 +206,7 @@ struct WgH {
     static constexpr int kARow = 34 * kARec, kGRow = 32 * kGRec;
     static constexpr int kOffA = kHGRing * kGRow;
     static constexpr int kOffMel = kOffA + 2 * kHRows * kARow;
-    static constexpr int kOffLut = kOffMel + 2 * kTMelFloats * 4;
+    static constexpr int kOffLut = kOffMel + 2 * 2 * kMelHPlane * 2;      // two clips x (hi, lo) f16 planes
     static constexpr int kLds = kOffLut + 256 * 16;
     static constexpr int kPartial = COUT * CIN * 9 + COUT;
 };
@@ -230,16 +214,18 @@ static_assert(WgH::kLds <= 160 * 1024 && WgH::kOffA % 16 == 0 && WgH::kOffMel % 
 
 __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __restrict__ mel, const uint8_t* __restrict__ maskbits,
                                                                const float* __restrict__ gp, int n, int width,
-                                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
+                                                               const float* __restrict__ b1, const float* __restrict__ rng,
                                                                float* __restrict__ partial) {
     using L = WgH;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* gring = ldsb;
     char* aring = ldsb + L::kOffA;
-    float* meltile = reinterpret_cast<float*>(ldsb + L::kOffMel);
+    _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + L::kOffMel);       // 2 clips x (hi plane, lo plane) of [82][36] f16
     u32x4* lut = reinterpret_cast<u32x4*>(ldsb + L::kOffLut);
-    __shared__ uint32_t melmax[2], w1l1, b1max;
-    __shared__ float clip_par[2][2];                           // per clip parity: 2^-a, 2^a
+    __shared__ uint32_t melmax[2];
+    __shared__ int clip_ea[2][2];                              // per clip parity: input exponent e, activation exponent a
+    __shared__ float clip_up[2];                               // 2^a / 2: the tile holds 2 relu(conv1) 2^-a
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,7 +234,7 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
     const int total = my_clips * kHSteps;
 
     for (int i = tid; i < L::kLds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;    // halo columns / dead columns stay zero
-    if (tid == 0) { melmax[0] = 0u; melmax[1] = 0u; w1l1 = 0u; b1max = 0u; }
+    if (tid == 0) { melmax[0] = 0u; melmax[1] = 0u; }
     __syncthreads();
     if (tid < 256) {
         u32x4 m;
@@ -256,49 +242,55 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
         for (int d = 0; d < 4; ++d) m[d] = ((tid >> (2 * d)) & 1 ? 0x3c00u : 0u) | ((tid >> (2 * d + 1)) & 1 ? 0x3c000000u : 0u);
         lut[tid] = m;
     }
-    // the bound max_c sum |w1[c]|, max |b1| behind the activation exponent
-    if (tid < 32) {
-        float l1 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) l1 += __builtin_fabsf(w1[tid * 9 + t]);
-        atomicMax(&w1l1, __float_as_uint(l1));
-        atomicMax(&b1max, __float_as_uint(__builtin_fabsf(b1[tid])));
-    }
-    auto load_mel = [&](int k, int t0, int nt) {               // clip k's tile, by threads t0 .. t0 + nt - 1
-        const float* src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kTH * width;
-        float* melt = meltile + (k & 1) * kTMelFloats;
+    // Model input of clip k -> two f16 planes (hi, lo) of x * 2^-e with a zero halo (the forward kernels' load_mel), in two stages
+    // separated by a workgroup barrier: the clip's max |x| (mel_max), then e, a and the planes (mel_planes).  Producer threads only:
+    // thread -> (column xx, rows y0 + 8 t).
+    const int ptid = tid - 512;
+    auto mel_max = [&](int k) {
+        const float* __restrict__ sp = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kTH * width + (ptid >> 5) * width + (ptid & 31);
         float mx = 0.f;
-        for (int i = tid - t0; i < kTH * width; i += nt) {
-            const int y = i / width, xx = i - y * width;
-            const float v = src[i];
-            melt[(y + 1) * kTMelRS + xx + 1] = v;
-            mx = fmaxf(mx, __builtin_fabsf(v));
+        if ((ptid & 31) < width) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) mx = fmaxf(mx, __builtin_fabsf(sp[8 * t * width]));
         }
         atomicMax(&melmax[k & 1], __float_as_uint(mx));
     };
-    auto set_clip_par = [&](int k) {                           // one thread, after the tile's barrier
-        const float bound = fmaf(__uint_as_float(melmax[k & 1]), __uint_as_float(w1l1), __uint_as_float(b1max));
-        const int a = clampi_h(exp_of_h(bound) - 13, -100, 100);
-        clip_par[k & 1][0] = pow2i_h(-a);
-        clip_par[k & 1][1] = pow2i_h(a);
+    auto mel_planes = [&](int k) {
+        const float mx = __uint_as_float(melmax[k & 1]);
+        const int e = clampi(exp_of(mx) - 14, -100, 113);
+        const int a = clampi(exp_of(fmaf(mx, rng[0], rng[1])) - 13, -100, 100);
+        if (ptid == 0) { clip_ea[k & 1][0] = e; clip_ea[k & 1][1] = a; clip_up[k & 1] = 0.5f * pow2i(a); }
+        const int xx = ptid & 31, y0 = ptid >> 5;
+        if (xx < width) {
+            const float* __restrict__ sp = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kTH * width + y0 * width + xx;
+            _Float16* dh = melh0 + (k & 1) * 2 * kMelHPlane + (y0 + 1) * kMelHRS + xx + 1;
+            const float down = pow2i(-e);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float vv = sp[8 * t * width] * down;
+                const _Float16 hi = static_cast<_Float16>(vv);
+                dh[8 * t * kMelHRS] = hi;
+                dh[8 * t * kMelHRS + kMelHPlane] = static_cast<_Float16>(vv - static_cast<float>(hi));
+            }
+        }
     };
-    load_mel(0, 0, 768);
+    if (!consumer) mel_max(0);
     __syncthreads();
-    if (tid == 0) set_clip_par(0);
+    if (!consumer) mel_planes(0);
     __syncthreads();
 
     if (!consumer) {
     // ================================================= producers =================================================
-    // conv1 weights of this producer thread (column x, channels 4 cg .. 4 cg + 3)
-    const int ptid = tid - 512;
-    const int x = ptid & 31, cg = (ptid >> 5) & 7;
-    float w1r[4][9], b1r[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w1r[u][t] = w1[(4 * cg + u) * 9 + t];
-        b1r[u] = b1[4 * cg + u];
-    }
+    // conv1 on the matrix cores (ww_conv1.h): producer wave pw makes a1 row 4 s + pw of every step
+    const int pw = wave - 8;
+    u32x4 w1h_r = w1H[lane], w1l_r = w1H[64 + lane];
+    asm volatile("" : "+v"(w1h_r), "+v"(w1l_r));
+    const half8 a1h = __builtin_bit_cast(half8, w1h_r), a1l = __builtin_bit_cast(half8, w1l_r);
+    const GatherLanes glanes = gather_lanes(lane & 31, lane >> 5);
+    const int s1_exp = -exp_of(hs1[0]);               // hs1[0] = 2^-S1
+    Conv1Scale cs;
+    const int x = lane & 31, h = lane >> 5;
+    const bool col_ok = x < width;
     const int mcol = ptid >> 3, mcg = ptid & 7;                  // mask role: column, byte (8 channels) of the position's 64 bits
     auto produce = [&](int gs) {
         const int k = gs / kHSteps, s = gs - k * kHSteps;
@@ -311,32 +303,33 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
             const int g = g0 + i;
             mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mcol) * 8 + mcg] : uint8_t(0);
         }
-        // a1 rows 4s .. 4s+3 -> half gs & 1 of the a ring
-        const float* melt = meltile + (k & 1) * kTMelFloats;
-        const float sc = clip_par[k & 1][0];
-        char* arow = aring + ((gs & 1) * kHRows) * L::kARow + (x + 1) * L::kARec + cg * 8;
-        const bool col_ok = x < width;
+        if (s == 0) {                                            // the clip's scales: bias in the accumulator's scale, descale
+            const int e = clip_ea[k & 1][0], a = clip_ea[k & 1][1];
 #pragma unroll
-        for (int i = 0; i < kHRows; ++i) {
-            const float* mp = melt + (kHRows * s + i) * kTMelRS + x;
-            const float m00 = mp[0], m01 = mp[1], m02 = mp[2], m10 = mp[kTMelRS], m11 = mp[kTMelRS + 1], m12 = mp[kTMelRS + 2],
-                        m20 = mp[2 * kTMelRS], m21 = mp[2 * kTMelRS + 1], m22 = mp[2 * kTMelRS + 2];
-            float v[4];
+            for (int j = 0; j < 16; ++j) cs.binit[j] = ldexpf(b1[16 * h + j], s1_exp - e);
+            cs.sc = ldexpf(1.0f, e - a - s1_exp);
+        }
+        // a1 row 4s + pw -> half gs & 1 of the a ring: 2 relu(conv1) 2^-a, split, the lane's 16 channels as 4 x 16 bytes
+        {
+            Conv1Row r;
+            conv1_row_gather(r, melh0 + (k & 1) * 2 * kMelHPlane, glanes, kHRows * s + pw);
+            conv1_row_mfma(r, a1h, a1l, cs);
+            if (col_ok) {
+                char* rec = aring + ((gs & 1) * kHRows + pw) * L::kARow + (x + 1) * L::kARec + h * 32;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float z = b1r[u];
-                z = fmaf(w1r[u][0], m00, z); z = fmaf(w1r[u][1], m01, z); z = fmaf(w1r[u][2], m02, z);
-                z = fmaf(w1r[u][3], m10, z); z = fmaf(w1r[u][4], m11, z); z = fmaf(w1r[u][5], m12, z);
-                z = fmaf(w1r[u][6], m20, z); z = fmaf(w1r[u][7], m21, z); z = fmaf(w1r[u][8], m22, z);
-                v[u] = (col_ok && z > 0.f) ? z * sc : 0.f;
+                for (int g8 = 0; g8 < 2; ++g8) {
+                    u32x4 vh, vl;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        uint32_t hh, ll;
+                        split2(relu2(r.acc[8 * g8 + 2 * d] * cs.sc), relu2(r.acc[8 * g8 + 2 * d + 1] * cs.sc), hh, ll);
+                        vh[d] = hh;
+                        vl[d] = ll;
+                    }
+                    *reinterpret_cast<u32x4*>(rec + g8 * 16) = vh;
+                    *reinterpret_cast<u32x4*>(rec + L::CIN * 2 + g8 * 16) = vl;
+                }
             }
-            u32x2 hi, lo;
-            uint32_t h0, l0, h1, l1;
-            split2_h(v[0], v[1], h0, l0);
-            split2_h(v[2], v[3], h1, l1);
-            hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
-            *reinterpret_cast<u32x2*>(arow + i * L::kARow) = hi;
-            *reinterpret_cast<u32x2*>(arow + i * L::kARow + L::CIN * 2) = lo;
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
@@ -346,14 +339,13 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
                 *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + mcol * L::kGRec + mcg * 16) = lut[mb[i]];
             }
         }
-        // the next clip's log-mel tile and exponent, well ahead of its first step (barriers separate the three stages)
+        // the next clip's planes and exponents, well ahead of its first step (barriers separate the three stages)
         if (k + 1 < my_clips) {
             if (s == 4 && ptid == 0) melmax[(k + 1) & 1] = 0u;
-            if (s == 8) load_mel(k + 1, 512, 256);
-            if (s == 12 && ptid == 0) set_clip_par(k + 1);
+            if (s == 8) mel_max(k + 1);
+            if (s == 12) mel_planes(k + 1);
         }
     };
-
     if (total > 0) produce(0);
     __syncthreads();
     for (int gs = 0; gs < total; ++gs) {
@@ -423,8 +415,8 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
             a_cur = a_next;
         }
         if (s == kHSteps - 1) {
-            // dW += gp[b, co] * (2^a S): D register j <-> co = 16 ct + 4 grp + j, lane & 15 <-> ci
-            const float up = clip_par[k & 1][1];
+            // dW += gp[b, co] * (2^a / 2) S (the tile holds 2 relu(conv1) 2^-a): D register j <-> co = 16 ct + 4 grp + j, lane & 15 <-> ci
+            const float up = clip_up[k & 1];
             const float gj[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int t = 0; t < 9; ++t)
@@ -476,11 +468,13 @@ int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hi
     return WW_OK;
 }
 
-int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* w1, const float* b1,
+int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* packed,
                          float* partial, int grid, hipStream_t st) {
     if (int rc = train_h_opt_in()) return rc;
+    const PackedLayout P = packed_layout(2);
     hipLaunchKernelGGL(conv2_wgrad_h_kernel, dim3(grid), dim3(768), WgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), gp, int(n),
-                       width, w1, b1, partial);
+                       width, reinterpret_cast<const u32x4*>(packed + P.conv1_h), packed + P.conv1_hs, packed + P.conv1_b, packed + P.range,
+                       partial);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
