@@ -685,14 +685,16 @@ static_assert(kWTileRows % 4 == 0, "four producers with equal shares");
 // OUT 1 (POOL): out = pooled [n][64].   OUT 0 (3-conv model): out = relu(conv2) as float32 [n][80 rows][32 columns][64 channels] (zero
 // beyond `width`) for cnn3w_kernel, and apow2[clip] = 2^a2, the exponent that kernel gives its transformed conv3 inputs.
 // OUT 2 (training forward of the 2-conv model): pooled as under OUT 1, plus bits[n][80][32] = 64 bits per position,
-// bit c = [relu(conv2)[c] > 0] (as 4 x uint16, one per N-tile): all the backward pass needs of relu(conv2) (ww_train_h.hip).
+// bit c = [relu(conv2)[c] > 0] (as 4 x uint16, one per N-tile), and bits1[n][80][32] = 32 bits per position, bit c = [relu(conv1)[c] > 0]
+// (2 x uint16, one per producer half-wave): all the backward pass needs of the activations (ww_train_h.hip).
 template <int OUT>
 __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__ mel, int n, int width,
                                                        const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
                                                        const float* __restrict__ b1,
                                                        const u32x4* __restrict__ wH, const float* __restrict__ hs,
                                                        const float* __restrict__ b2, const float* __restrict__ rng,
-                                                       float* __restrict__ out, float* __restrict__ apow2, uint16_t* __restrict__ bits) {
+                                                       float* __restrict__ out, float* __restrict__ apow2, uint16_t* __restrict__ bits,
+                                                       uint16_t* __restrict__ bits1) {
     constexpr bool POOL = OUT != 0, BITS = OUT == 2;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* act0 = ldsb;
@@ -828,6 +830,19 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                 if (i == 0) conv1_rows2(plane, 2 * t - 1, d0, d1);
                 else { d0 = d2; d1 = d3; }                                    // rows 2t-1, 2t are the previous tile row's 2t'+1, 2t'+2
                 conv1_rows2(plane, 2 * t + 1, d2, d3);
+                if constexpr (BITS) {
+                    // sign bits of conv1, every image row once: rows 2t+1, 2t+2 here; row 0 by the first producer's first tile row
+                    auto sign16 = [&](const f32x16& v) {
+                        uint32_t m = 0u;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) m |= (col_ok && v[j] > 0.f) ? (1u << j) : 0u;
+                        return uint16_t(m);
+                    };
+                    uint16_t* o1 = bits1 + (((int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kH) * kW + x) * 2 + h;
+                    if (t == 0 && i == 0) o1[0] = sign16(d1);
+                    o1[(2 * t + 1) * kW * 2] = sign16(d2);
+                    if (2 * t + 2 < kH) o1[(2 * t + 2) * kW * 2] = sign16(d3);
+                }
 #endif
                 flag_wait(&free_cnt[b], 4u * unsigned(q / kWRing), &wg_bad);  // the group's four waves are done with the buffer's previous tile row
 #ifndef WW_ABL_NOPROD
@@ -1348,7 +1363,8 @@ static int opt_in_lds() {
 
 // training forward of the 2-conv model in split precision (ww_train.hip): the inference kernel with the ReLU mask as a second output.
 // `packed`: a packed image whose conv1 / conv2-Winograd / range entries were written on the device from the live parameters.
-int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, hipStream_t stream) {
+int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, uint32_t* bits1,
+                           hipStream_t stream) {
     if (n == 0) return WW_OK;
     const PackedLayout L = packed_layout(2);
     if (int rc = opt_in_lds()) return rc;
@@ -1356,7 +1372,7 @@ int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* 
     hipLaunchKernelGGL(cnn2w_kernel<2>, dim3(int(n < cus ? n : cus)), dim3(768), kCWLds, stream, mel, int(n), width,
                        reinterpret_cast<const u32x4*>(packed + L.conv1_h), packed + L.conv1_hs, packed + L.conv1_b,
                        reinterpret_cast<const u32x4*>(packed + L.conv2_hw), packed + L.conv2_hws, packed + L.conv2_b, packed + L.range, pooled,
-                       static_cast<float*>(nullptr), reinterpret_cast<uint16_t*>(bits));
+                       static_cast<float*>(nullptr), reinterpret_cast<uint16_t*>(bits), reinterpret_cast<uint16_t*>(bits1));
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
@@ -1400,14 +1416,15 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
             if (n_conv == 2) {
                 hipLaunchKernelGGL(cnn2w_kernel<true>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
                                    packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
-                                   packed + L.range, pooled, static_cast<float*>(nullptr), static_cast<uint16_t*>(nullptr));
+                                   packed + L.range, pooled, static_cast<float*>(nullptr), static_cast<uint16_t*>(nullptr),
+                                   static_cast<uint16_t*>(nullptr));
                 WW_HIP(hipGetLastError());
                 return WW_OK;
             }
             float* apw = reinterpret_cast<float*>(static_cast<char*>(scratch) + mid_bytes(n));
             hipLaunchKernelGGL(cnn2w_kernel<false>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
                                packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
-                               packed + L.range, static_cast<float*>(scratch), apw, static_cast<uint16_t*>(nullptr));
+                               packed + L.range, static_cast<float*>(scratch), apw, static_cast<uint16_t*>(nullptr), static_cast<uint16_t*>(nullptr));
             WW_HIP(hipGetLastError());
             hipLaunchKernelGGL(cnn3w_kernel, dim3(grid1), dim3(512), kC3wLds, stream, static_cast<const float*>(scratch),
                                static_cast<const float*>(apw), int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_hw),

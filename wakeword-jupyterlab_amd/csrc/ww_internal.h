@@ -142,9 +142,15 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
 int train_math_mode();   // 0 exact fp32, 1 split-precision conv backward where a kernel exists (ww_train_h.hip)
 int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st);
 int launch_pack_conv_h_dev(const float* w1, const float* b1, const float* w2, const float* b2, float* img, hipStream_t st);
-int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, hipStream_t stream);
+int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, uint32_t* bits1,
+                           hipStream_t stream);
 int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* packed,
                          float* partial, int grid, hipStream_t st);
+
+int64_t dgrad_h_scratch_floats(int64_t n);
+int launch_gp_max(const float* dpooled, float s, int64_t n, float* gp, float* scratch, hipStream_t st);
+int launch_conv2_dgrad_h(const float* mel, const uint32_t* maskbits, const uint32_t* bits1, const float* gp, const float* w2, float* scratch,
+                         int64_t n, int width, float* partial, int grid, hipStream_t st);
 
 int require_gfx950();
 int device_cu_count();   // CUs of the current device (256 on MI355X); cached

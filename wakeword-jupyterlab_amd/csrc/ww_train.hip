@@ -575,6 +575,8 @@ struct TrainWs {
     float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *partial, *reduced;
     uint32_t* maskbits;                                  // [n][80][32][c_last / 32]: [relu(last conv) > 0]
     float* wpk;                                          // 2-conv model, split precision: packed image written on the device
+    uint32_t* bits1;                                     // 2-conv model, split precision: [n][80][32] sign bits of conv1
+    float* dgh;                                          // scratch of the split-precision data-gradient kernel
     int64_t total;
 };
 static int64_t a256(int64_t floats) { return (floats * 4 + 255) / 256 * 64; }      // floats, 256-byte granules
@@ -601,6 +603,8 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     w.reduced = take(n_conv == 3 ? kWg3Partial : kWg2Partial);
     w.maskbits = reinterpret_cast<uint32_t*>(take(n * kTH * kTW * (c_last / 32)));
     w.wpk = n_conv == 2 ? take(packed_layout(2).total) : nullptr;
+    w.bits1 = n_conv == 2 ? reinterpret_cast<uint32_t*>(take(n * kTH * kTW)) : nullptr;
+    w.dgh = n_conv == 2 ? take(dgrad_h_scratch_floats(n)) : nullptr;
     w.total = o * 4;
     return w;
 }
@@ -653,7 +657,7 @@ int train_forward(const float* mel, int64_t n, int width, const ww_train_params*
         // relu(conv2) itself is never stored.  The backward pass must run under the same arithmetic (it reads the mask bits).
         WW_HIP(hipMemsetAsync(w.wpk, 0, sizeof(float) * packed_layout(2).total, st));
         if (int rc = launch_pack_conv_h_dev(p->conv_weight[0], p->conv_bias[0], p->conv_weight[1], p->conv_bias[1], w.wpk, st)) return rc;
-        if (int rc = launch_cnn2w_pool_bits(mel, n, width, w.wpk, w.pooled, w.maskbits, st)) return rc;
+        if (int rc = launch_cnn2w_pool_bits(mel, n, width, w.wpk, w.pooled, w.maskbits, w.bits1, st)) return rc;
         return launch_lstm_fc_train(w.pooled, n, c_last, p->lstm_weight_ih[0], p->lstm_bias_ih[0], p->lstm_bias_hh[0], p->lstm_weight_ih[1],
                                     p->lstm_bias_ih[1], p->lstm_bias_hh[1], p->fc_weight, p->fc_bias, w.lstm_packed, w.gates0, w.mask0, w.hd0,
                                     w.gates1, w.mask1, w.hd1, p_lstm, p_fc, seed, logits, st);
@@ -706,8 +710,12 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     sgemm(w.dg0, 1, 4 * H, w.pooled, c_last, 1, g->lstm_weight_ih[0], c_last, 4 * H, c_last, N, st);       // [1024][C] = dg0^T pooled
     hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(1024), 0, st, w.dg0, N, 4 * H, g->lstm_bias[0]);
     sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], c_last, 1, w.dpooled, c_last, N, c_last, 4 * H, st);      // [n][C] = dg0 W_ih_l0
-    hipLaunchKernelGGL(scale_kernel, dim3(256), dim3(256), 0, st, w.dpooled, 1.0f / float(kTH * width), n * c_last, w.gp);
-    WW_HIP(hipGetLastError());
+    if (split) {
+        if (int rc = launch_gp_max(w.dpooled, 1.0f / float(kTH * width), n, w.gp, w.dgh, st)) return rc;
+    } else {
+        hipLaunchKernelGGL(scale_kernel, dim3(256), dim3(256), 0, st, w.dpooled, 1.0f / float(kTH * width), n * c_last, w.gp);
+        WW_HIP(hipGetLastError());
+    }
     // conv stack, top down.  The last conv feeds the pool (rank-one gradient gp * [act > 0]); below it the gradient is dense.
     const float* w1 = p->conv_weight[0];
     const float* b1 = p->conv_bias[0];
@@ -735,11 +743,9 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     if (nc == 3)
         hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, true, true>), dim3(grid), dim3(256), kDg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.dgrad2_b_op, w.partial);
-    else if (split)
-        hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, false, true, true>), dim3(grid), dim3(256), kDg2Lds, st,
-                           mel, static_cast<const float*>(nullptr), reinterpret_cast<const float*>(w.maskbits), w.gp, N, width, w1, b1,
-                           w.dgrad2_b_op, w.partial);
-    else
+    else if (split) {
+        if (int rc = launch_conv2_dgrad_h(mel, w.maskbits, w.bits1, w.gp, p->conv_weight[1], w.dgh, n, width, w.partial, grid, st)) return rc;
+    } else
         hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, false, true>), dim3(grid), dim3(256), kDg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.mid2, w.gp, N, width, w1, b1, w.dgrad2_b_op, w.partial);
     WW_HIP(hipGetLastError());

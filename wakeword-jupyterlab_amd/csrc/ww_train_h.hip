@@ -449,6 +449,231 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Data gradient of conv2 and, from it, the weight gradient of conv1 -- the first layer: da1 is consumed where it is produced.
+//   da1[ci][y][x] = sum_{co,dy,dx} mask2[co][y-dy+1][x-dx+1] * G[co][ci][dy][dx],     G = gp[b,co] * W2   (rebuilt per clip)
+//   D[m = column][n = ci] += A[m][k] B[k][n] on v_mfma_f32_16x16x32_f16, k = 32 of the 64 co of one tap:
+//   A = mask2 at the shifted position (exact 0/1, one ds_read_b128 of the channels-last record), B = G 2^-eg as hi + lo: two MFMAs.
+//   dz1 = da1 * [relu(conv1) > 0]  (the forward's sign bits);  dW1[ci][t] = sum_pos dz1[ci][pos] * mel[pos + t],  db1 = sum dz1
+//   as v_mfma_f64_16x16x4_f64 (M = ci, N = the 9 taps + a column of ones, K = four positions): a conv1 weight gradient is a sum of
+//   ~10^5 products with heavy cancellation -- double accumulation, now on the matrix pipe instead of 18 vector instructions per element.
+// 8 waves (256 VGPRs each) = (16 ci) x (row of a four-row step); the wave's 18 k-steps x (hi, lo) = 144 B-operand VGPRs are rebuilt
+// at the start of every clip from the pre-ordered fp32 weights (L1/L2) times the clip's gp, scaled by 2^-eg (eg from max|gp[b]| max|W2|).
+// All 512 threads fill the next step's mask rows (bit image -> LUT -> 160-byte records) and conv1 sign rows; one barrier per step.
+// Output: one partial [32][9] + [32] (float; summed over the workgroup in double) per workgroup -> reduce_partials_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef double double4v __attribute__((ext_vector_type(4)));
+struct DgH {
+    static constexpr int CIN = 32, COUT = 64;
+    static constexpr int kGRec = 160, kGRow = 34 * kGRec;                   // columns -1..32, conflict-free 16-byte row reads
+    static constexpr int kMelRS = 36, kMelFloats = (kTH + 2) * kMelRS;      // fp32 log-mel tile with a zero halo
+    static constexpr int kOffMel = kHGRing * kGRow;
+    static constexpr int kOffS1 = kOffMel + 2 * kMelFloats * 4;             // conv1 sign words: 2 steps x 4 rows x 32 columns
+    static constexpr int kOffLut = kOffS1 + 2 * kHRows * kTW * 4;
+    static constexpr int kLds = kOffLut + 256 * 16;
+    static constexpr int kPartial = CIN * 9 + CIN;
+};
+static_assert(DgH::kLds <= 160 * 1024 && DgH::kOffMel % 16 == 0 && DgH::kOffS1 % 16 == 0 && DgH::kOffLut % 16 == 0, "LDS map");
+
+// W2 [64][32][3][3] -> the lane order of the B operand: wp[((nt*18 + ks)*64 + lane)*8 + j] = W2[32 kb + 8 g + j][16 nt + n][dy][dx],
+// ks = (dy*3 + dx)*2 + kb, lane = n + 16 g; wmax = max |W2| (float bits, zeroed by the caller)
+__global__ void pack_dgrad_h_dev_kernel(const float* __restrict__ w2, float* __restrict__ wp, unsigned int* __restrict__ wmax) {
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 18 * 64 * 8; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 18, nt = i / (18 * 512);
+        const int kb = ks & 1, tap = ks >> 1, co = 32 * kb + 8 * (lane >> 4) + j, ci = 16 * nt + (lane & 15);
+        const float v = w2[(co * 32 + ci) * 9 + tap];
+        wp[i] = v;
+        m = fmaxf(m, __builtin_fabsf(v));
+    }
+    atomicMax(wmax, __float_as_uint(m));
+}
+// gp[b][co] = dpooled[b][co] * s, gpmax[b] = max_co |gp[b][co]|: one wave per clip (64 channels)
+__global__ void gp_max_kernel(const float* __restrict__ dpooled, float s, int n, float* __restrict__ gp, float* __restrict__ gpmax) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n) return;
+    const float v = dpooled[int64_t(b) * 64 + lane] * s;
+    gp[int64_t(b) * 64 + lane] = v;
+    float m = __builtin_fabsf(v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) gpmax[b] = m;
+}
+
+__global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __restrict__ mel, const uint8_t* __restrict__ maskbits,
+                                                               const uint32_t* __restrict__ bits1, const float* __restrict__ gp,
+                                                               const float* __restrict__ gpmax, const float* __restrict__ wp,
+                                                               const float* __restrict__ w2max, int n, int width,
+                                                               float* __restrict__ partial) {
+    using L = DgH;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* gring = ldsb;
+    float* meltile = reinterpret_cast<float*>(ldsb + L::kOffMel);
+    uint32_t* s1rows = reinterpret_cast<uint32_t*>(ldsb + L::kOffS1);
+    u32x4* lut = reinterpret_cast<u32x4*>(ldsb + L::kOffLut);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1, rg = wave >> 1;                       // 16 ci x row of the step
+    const int ln = lane & 15, grp = lane >> 4;
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int total = my_clips * kHSteps;
+
+    for (int i = tid; i < L::kLds / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;      // halo columns stay zero
+    __syncthreads();
+    if (tid < 256) {
+        u32x4 m;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) m[d] = ((tid >> (2 * d)) & 1 ? 0x3c00u : 0u) | ((tid >> (2 * d + 1)) & 1 ? 0x3c000000u : 0u);
+        lut[tid] = m;
+    }
+    auto load_mel = [&](int k) {
+        const float* src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kTH * width;
+        float* melt = meltile + (k & 1) * L::kMelFloats;
+        for (int i = tid; i < kTH * width; i += 512) {
+            const int y = i / width, xx = i - y * width;
+            melt[(y + 1) * L::kMelRS + xx + 1] = src[i];
+        }
+    };
+    // the rows a step needs beyond what is already in LDS: mask rows 0..4 (first step of a clip) or 4s+1..4s+4, conv1 sign rows 4s..4s+3
+    const int mcg = tid & 7, mpos = tid >> 3;                       // mask role: byte (8 channels), position 0..63 (+64 per pass)
+    uint8_t mb[3];
+    uint32_t sw_next = 0u;
+    auto fill_load = [&](int gs) {                                 // issue the global loads early ...
+        const int k = gs / kHSteps, s = gs - k * kHSteps;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const int g0 = s == 0 ? 0 : 4 * s + 1, g1 = 4 * s + 4 < kTH ? 4 * s + 4 : kTH - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
+            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + (pos & 31)) * 8 + mcg] : uint8_t(0);
+        }
+        if (tid < kHRows * kTW) sw_next = bits1[(clip * kTH + kHRows * s) * kTW + tid];
+    };
+    auto fill_store = [&](int gs) {                                // ... and expand them into LDS behind the step's matrix work
+        const int k = gs / kHSteps, s = gs - k * kHSteps;
+        const int g0 = s == 0 ? 0 : 4 * s + 1, g1 = 4 * s + 4 < kTH ? 4 * s + 4 : kTH - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
+            if (g <= g1) {
+                const int slot = (k * kTH + g) % kHGRing;
+                *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + ((pos & 31) + 1) * L::kGRec + mcg * 16) = lut[mb[i]];
+            }
+        }
+        if (tid < kHRows * kTW) s1rows[(gs & 1) * kHRows * kTW + tid] = sw_next;
+        if (s == 8 && k + 1 < my_clips) load_mel(k + 1);
+    };
+
+    // B operand of this wave: G[k-step][hi, lo], rebuilt per clip
+    half8 bh[18], bl[18];
+    double4v dacc = {0., 0., 0., 0.};                               // dW1 / db1: row (register j) ci = 4 j + grp, column (lane & 15) = tap, 9 = bias
+    float dscale = 0.f;
+    auto rebuild = [&](int k) {
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const int eg = clampi(exp_of(gpmax[clip] * w2max[0]) - 12, -100, 100);
+        const float down = pow2i(-eg);
+        dscale = pow2i(eg);
+        float gv[16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const float4 v = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 32 * kb + 8 * grp + 4 * q4);
+                gv[8 * kb + 4 * q4] = v.x * down; gv[8 * kb + 4 * q4 + 1] = v.y * down; gv[8 * kb + 4 * q4 + 2] = v.z * down; gv[8 * kb + 4 * q4 + 3] = v.w * down;
+            }
+        const float4* w4 = reinterpret_cast<const float4*>(wp) + (int64_t(nt) * 18 * 64 + lane) * 2;
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            const float4 wa = w4[ks * 128], wb = w4[ks * 128 + 1];
+            const int kb = ks & 1;
+            const float g0 = wa.x * gv[8 * kb], g1 = wa.y * gv[8 * kb + 1], g2 = wa.z * gv[8 * kb + 2], g3 = wa.w * gv[8 * kb + 3],
+                        g4 = wb.x * gv[8 * kb + 4], g5 = wb.y * gv[8 * kb + 5], g6 = wb.z * gv[8 * kb + 6], g7 = wb.w * gv[8 * kb + 7];
+            u32x4 vh, vl;
+            uint32_t hh, ll;
+            split2(g0, g1, hh, ll); vh[0] = hh; vl[0] = ll;
+            split2(g2, g3, hh, ll); vh[1] = hh; vl[1] = ll;
+            split2(g4, g5, hh, ll); vh[2] = hh; vl[2] = ll;
+            split2(g6, g7, hh, ll); vh[3] = hh; vl[3] = ll;
+            bh[ks] = __builtin_bit_cast(half8, vh);
+            bl[ks] = __builtin_bit_cast(half8, vl);
+        }
+    };
+
+    load_mel(0);
+    if (total > 0) fill_load(0);
+    __syncthreads();                                               // the LUT is complete
+    if (total > 0) fill_store(0);
+    __syncthreads();
+    const char* abase = gring + (ln + 1) * L::kGRec + grp * 16;       // A: row = column ln of the m-tile, k = 8 channels of the lane group
+    for (int gs = 0; gs < total; ++gs) {
+        const int k = gs / kHSteps, s = gs - k * kHSteps;
+        if (s == 0) rebuild(k);
+        if (gs + 1 < total) fill_load(gs + 1);
+        const int y = kHRows * s + rg;
+        f32x4 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mt][j] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + 1 - dy;                              // mask row of tap dy
+            if (yy >= 0 && yy < kTH) {                              // wave-uniform
+                const char* rowp = abase + ((k * kTH + yy) % kHGRing) * L::kGRow;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const int ks = (dy * 3 + dx) * 2 + kb;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const half8 a = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp + (16 * mt + 1 - dx) * L::kGRec + kb * 64));
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[ks], acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl[ks], acc[mt], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+        // epilogue: D register j <-> column 16 mt + 4 grp + j, lane & 15 <-> ci = 16 nt + ln
+        const float* melt = meltile + (k & 1) * L::kMelFloats;
+        const uint32_t* s1 = s1rows + ((gs & 1) * kHRows + rg) * kTW;
+        const int tap = ln, ty = tap / 3, tx = tap - 3 * ty;
+        const float* mp = melt + (y + ty) * L::kMelRS + tx;           // + column: taps of position (y, col) are tile rows y..y+2, columns col..col+2
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const u32x4 sw = *reinterpret_cast<const u32x4*>(s1 + 16 * mt + 4 * grp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 16 * mt + 4 * grp + j;
+                const bool live = (sw[j] >> (16 * nt + ln)) & 1u;
+                const double a64 = live ? double(acc[mt][j] * dscale) : 0.0;
+                const float mv = tap < 9 ? mp[col] : (tap == 9 ? 1.0f : 0.f);
+                dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a64, double(mv), dacc, 0, 0, 0);
+            }
+        }
+        if (gs + 1 < total) fill_store(gs + 1);
+        __syncthreads();
+    }
+    // the four row waves of a ci tile, in fixed order -> this workgroup's partial
+    double* red = reinterpret_cast<double*>(ldsb);                   // [8 waves][4][64]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(wave * 4 + j) * 64 + lane] = dacc[j];
+    __syncthreads();
+    if (rg == 0 && ln < 10) {
+        float* outp = partial + int64_t(blockIdx.x) * L::kPartial;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += red[((2 * r + nt) * 4 + j) * 64 + lane];
+            const int ci = 16 * nt + 4 * j + grp;
+            if (ln < 9) outp[ci * 9 + ln] = float(sum);
+            else outp[L::CIN * 9 + ci] = float(sum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int train_h_opt_in() {
@@ -458,6 +683,7 @@ static int train_h_opt_in() {
     if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
     if (done[dev]) return WW_OK;
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WgH::kLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DgH::kLds));
     done[dev] = true;
     return WW_OK;
 }
@@ -475,6 +701,30 @@ int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float
     hipLaunchKernelGGL(conv2_wgrad_h_kernel, dim3(grid), dim3(768), WgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), gp, int(n),
                        width, reinterpret_cast<const u32x4*>(packed + P.conv1_h), packed + P.conv1_hs, packed + P.conv1_b, packed + P.range,
                        partial);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// dgrad scratch (floats): wp [2*18*64*8], wmax [4], gpmax [n]
+int64_t dgrad_h_scratch_floats(int64_t n) { return 2 * 18 * 64 * 8 + 4 + ((n + 3) & ~int64_t(3)); }
+
+int launch_gp_max(const float* dpooled, float s, int64_t n, float* gp, float* scratch, hipStream_t st) {
+    float* gpmax = scratch + 2 * 18 * 64 * 8 + 4;
+    hipLaunchKernelGGL(gp_max_kernel, dim3(unsigned((n + 3) / 4)), dim3(256), 0, st, dpooled, s, int(n), gp, gpmax);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+int launch_conv2_dgrad_h(const float* mel, const uint32_t* maskbits, const uint32_t* bits1, const float* gp, const float* w2, float* scratch,
+                         int64_t n, int width, float* partial, int grid, hipStream_t st) {
+    if (int rc = train_h_opt_in()) return rc;
+    float* wp = scratch;
+    float* wmax = scratch + 2 * 18 * 64 * 8;
+    float* gpmax = wmax + 4;
+    WW_HIP(hipMemsetAsync(wmax, 0, 16, st));
+    hipLaunchKernelGGL(pack_dgrad_h_dev_kernel, dim3(36), dim3(256), 0, st, w2, wp, reinterpret_cast<unsigned int*>(wmax));
+    hipLaunchKernelGGL(conv2_dgrad_h_kernel, dim3(grid), dim3(512), DgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), bits1, gp,
+                       gpmax, wp, wmax, int(n), width, partial);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
