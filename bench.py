@@ -374,6 +374,8 @@ def main():
             # one training step of the same model (forward in train mode + backward + Adam)
             import bench_train
             out["training"] = bench_train.measure(batch=B, steps=5, device=dev.index)
+            out["training"]["exact_fp32_ms_per_step"] = bench_train.measure(batch=B, steps=3, device=dev.index, math="f32", cpu_sample=8)["ms_per_step"]
+            bench_train.ops_reset_train_math()
             out["training_3conv"] = bench_train.measure(batch=2048, steps=3, device=dev.index, arch="full", cpu_sample=16)
         print(json.dumps(out))
     if world > 1:

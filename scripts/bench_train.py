@@ -11,9 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(batch=4096, steps=5, device=0, cpu_sample=64, arch="simple"):
+def measure(batch=4096, steps=5, device=0, cpu_sample=64, arch="simple", math=None):
     import wakeword_jupyterlab_amd as pkg
     from oracle import model_oracle
+    from wakeword_jupyterlab_amd import ops
+    if math:
+        ops.set_train_math(math)
+    math = ops.get_train_math()
     dev = torch.device("cuda", device)
     sd = pkg.synth.make_state_dict(arch, seed=1234)
     m = pkg.SimpleWakewordModel() if arch == "simple" else pkg.WakewordModel()
@@ -49,10 +53,19 @@ def measure(batch=4096, steps=5, device=0, cpu_sample=64, arch="simple"):
         opt_r.step()
     dt_cpu = (time.perf_counter() - t1) / 2
     return {"workload": f"{'SimpleWakewordModel' if arch == 'simple' else '3-conv WakewordModel'} training step (train-mode forward with dropout + CrossEntropyLoss + backward + Adam), "
-                        f"batch {batch}, log-mel inputs resident in HBM; exact fp32 kernels (csrc/ww_train.hip)",
+                        f"batch {batch}, log-mel inputs resident in HBM; " +
+                        ("conv stack in split precision on the f16 matrix cores, conv1 weight gradient on the f64 matrix cores, head exact fp32 "
+                         "(csrc/ww_train_h.hip, ww_train.hip)" if math == "f16x3" and arch == "simple" else "exact fp32 kernels (csrc/ww_train.hip)"),
+            "train_math": math if arch == "simple" else "f32",
             "ms_per_step": dt * 1e3, "clips_per_s": batch / dt, "final_loss": float(loss.item()),
             "cpu_torch_clips_per_s": cpu_sample / dt_cpu, "cpu_threads": int(torch.get_num_threads()), "cpu_sample": cpu_sample}
 
 
+def ops_reset_train_math():
+    from wakeword_jupyterlab_amd import ops
+    ops.set_train_math("f16x3")
+
+
 if __name__ == "__main__":
-    print(measure(arch=sys.argv[1] if len(sys.argv) > 1 else "simple", batch=int(sys.argv[2]) if len(sys.argv) > 2 else 4096))
+    print(measure(arch=sys.argv[1] if len(sys.argv) > 1 else "simple", batch=int(sys.argv[2]) if len(sys.argv) > 2 else 4096,
+                  math=sys.argv[3] if len(sys.argv) > 3 else None))
