@@ -240,7 +240,8 @@ WW_API int ww_forward_pcm_f32(const float* pcm_dev, int64_t n_clips, int64_t cli
  * (wakeword_training/train_wakeword.py:109-115; WakewordTrainer.train_epoch, wakeword_training_script.py:241-267) for
  * SimpleWakewordModel and the 3-conv WakewordModel: the forward with nn.LSTM's inter-layer dropout and nn.Dropout before fc (train_wakeword.py:34-35,
  * 46-47), and d loss / d parameter given d loss / d logits.  CrossEntropyLoss and the optimiser stay with the caller.
- * Exact fp32 (f32 MFMA / VALU).  All pointers in the two structs are DEVICE pointers in torch layout (the live parameters
+ * Arithmetic: ww_set_train_math below (exact fp32, or the conv stack of the 2-conv model in split precision on the f16 / f64 matrix cores).
+ * All pointers in the two structs are DEVICE pointers in torch layout (the live parameters
  * and their .grad buffers): nothing is packed on the host, the weights may change between calls.
  * Dropout factors come from a counter-based generator keyed by (seed, layer, clip, unit): the same seed reproduces the
  * step; torch's own random stream cannot be matched (documented, tests/test_gpu_train.py). */

@@ -1,5 +1,6 @@
 // v_mfma_f64_16x16x4_f64 operand / result layout check: A[m][k] = 1 + m + 100 k, B[k][n] = 1 + n + 1000 k with the assumed layouts
 // (A: lane = m + 16 k; B: lane = n + 16 k; D register j of lane l <-> row 4 (l / 16) + j, column l % 16); prints the mismatches.
+// Result on MI355X: A and B as assumed; D register j of lane l <-> row 4 j + l / 16, column l % 16 (what conv2_dgrad_h_kernel uses).
 // build: hipcc --offload-arch=gfx950 -O2 -o scripts/ubench/build/mfma_f64 scripts/ubench/mfma_f64.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
