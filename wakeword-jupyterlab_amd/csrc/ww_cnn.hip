@@ -687,6 +687,7 @@ static_assert(kWTileRows % 4 == 0, "four producers with equal shares");
 // OUT 2 (training forward of the 2-conv model): pooled as under OUT 1, plus bits[n][80][32] = 64 bits per position,
 // bit c = [relu(conv2)[c] > 0] (as 4 x uint16, one per N-tile), and bits1[n][80][32] = 32 bits per position, bit c = [relu(conv1)[c] > 0]
 // (2 x uint16, one per producer half-wave): all the backward pass needs of the activations (ww_train_h.hip).
+// OUT 3 (training forward of the 3-conv model): relu(conv2) and apow2 as under OUT 0, plus bits1.
 template <int OUT>
 __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__ mel, int n, int width,
                                                        const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                                                        const float* __restrict__ b2, const float* __restrict__ rng,
                                                        float* __restrict__ out, float* __restrict__ apow2, uint16_t* __restrict__ bits,
                                                        uint16_t* __restrict__ bits1) {
-    constexpr bool POOL = OUT != 0, BITS = OUT == 2;
+    constexpr bool POOL = OUT == 1 || OUT == 2, BITS = OUT == 2, BITS1 = OUT == 2 || OUT == 3;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* act0 = ldsb;
     _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + kWNB * kWBuf);      // 2 clips x (hi plane, lo plane) of [82][36] f16
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                 if (i == 0) conv1_rows2(plane, 2 * t - 1, d0, d1);
                 else { d0 = d2; d1 = d3; }                                    // rows 2t-1, 2t are the previous tile row's 2t'+1, 2t'+2
                 conv1_rows2(plane, 2 * t + 1, d2, d3);
-                if constexpr (BITS) {
+                if constexpr (BITS1) {
                     // sign bits of conv1, every image row once: rows 2t+1, 2t+2 here; row 0 by the first producer's first tile row
                     auto sign16 = [&](const f32x16& v) {
                         uint32_t m = 0u;
@@ -1004,9 +1005,11 @@ constexpr int kW3Plane = kRS * kW3Rec;              // 9,792
 constexpr int kW3Buf = 4 * kW3Plane;                // 39,168
 constexpr int kC3wLds = 2 * kW3Buf;
 
+// BITS (training forward): also bits3[n][80][32] = 128 bits per position, bit c = [relu(conv3)[c] > 0] (8 x uint16, one per N-tile).
+template <bool BITS>
 __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__ mid, const float* __restrict__ apow2, int n, int width,
                                                        const u32x4* __restrict__ wH, const float* __restrict__ hs,
-                                                       const float* __restrict__ b3, float* __restrict__ out) {
+                                                       const float* __restrict__ b3, float* __restrict__ out, uint16_t* __restrict__ bits3) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int nt = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1097,12 +1100,28 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
                 acc[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[xi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            unsigned long long live0[4], live1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float m12 = acc[1][j] + acc[2][j], m1m2 = acc[1][j] - acc[2][j];
                 const float y0 = acc[0][j] + m12, y1 = m1m2 - acc[3][j];
-                const float v = relu2(fmaf(y0, dsc, bias)) + relu2(fmaf(y1, dsc, bias));
-                pool += (width == kW || 16 * c + 4 * kq + j < width) ? v : 0.f;
+                const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
+                const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
+                pool += col_live ? v0 + v1 : 0.f;
+                if constexpr (BITS) {           // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
+                    live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
+                    live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
+                }
+            }
+            if constexpr (BITS) {               // lane (kq, pi < 4) stores the 16 channel bits of column 16 c + 4 kq + pi, both rows
+                const unsigned long long s0 = pi == 0 ? live0[0] : (pi == 1 ? live0[1] : (pi == 2 ? live0[2] : live0[3]));
+                const unsigned long long s1 = pi == 0 ? live1[0] : (pi == 1 ? live1[1] : (pi == 2 ? live1[2] : live1[3]));
+                if (pi < 4) {
+                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                    uint16_t* o = bits3 + ((clip * kH + 2 * t) * kW + 16 * c + 4 * kq + pi) * 8 + nt;
+                    o[0] = uint16_t(s0 >> (16 * kq));
+                    o[kW * 8] = uint16_t(s1 >> (16 * kq));
+                }
             }
             // the next tile row goes into the OTHER buffer (last read in step g-1) between the two column halves: its loads have
             // landed by now, and this wave's transform + stores run under its SIMD sibling's MFMAs instead of in front of the barrier
@@ -1351,7 +1370,9 @@ static int opt_in_lds() {
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
-    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                int(sizeof(float) * kC3LdsFloats)));
@@ -1373,6 +1394,27 @@ int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* 
                        reinterpret_cast<const u32x4*>(packed + L.conv1_h), packed + L.conv1_hs, packed + L.conv1_b,
                        reinterpret_cast<const u32x4*>(packed + L.conv2_hw), packed + L.conv2_hws, packed + L.conv2_b, packed + L.range, pooled,
                        static_cast<float*>(nullptr), reinterpret_cast<uint16_t*>(bits), reinterpret_cast<uint16_t*>(bits1));
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// training forward of the 3-conv model in split precision: the inference kernels; relu(conv2) stays in `mid2` as float32
+// [n][80 rows][32 columns][64 channels], the ReLU mask of conv3 and the sign bits of conv1 as bit images.
+int launch_cnn3w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* mid2, float* apow2, float* pooled,
+                           uint32_t* bits3, uint32_t* bits1, hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    const PackedLayout L = packed_layout(3);
+    if (int rc = opt_in_lds()) return rc;
+    const int cus = device_cu_count();
+    const int grid1 = int(n < cus ? n : cus);
+    hipLaunchKernelGGL(cnn2w_kernel<3>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width,
+                       reinterpret_cast<const u32x4*>(packed + L.conv1_h), packed + L.conv1_hs, packed + L.conv1_b,
+                       reinterpret_cast<const u32x4*>(packed + L.conv2_hw), packed + L.conv2_hws, packed + L.conv2_b, packed + L.range, mid2,
+                       apow2, static_cast<uint16_t*>(nullptr), reinterpret_cast<uint16_t*>(bits1));
+    WW_HIP(hipGetLastError());
+    hipLaunchKernelGGL(cnn3w_kernel<true>, dim3(grid1), dim3(512), kC3wLds, stream, static_cast<const float*>(mid2),
+                       static_cast<const float*>(apow2), int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_hw),
+                       packed + L.conv3_hws, packed + L.conv3_b, pooled, reinterpret_cast<uint16_t*>(bits3));
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
@@ -1426,9 +1468,9 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
                                packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
                                packed + L.range, static_cast<float*>(scratch), apw, static_cast<uint16_t*>(nullptr), static_cast<uint16_t*>(nullptr));
             WW_HIP(hipGetLastError());
-            hipLaunchKernelGGL(cnn3w_kernel, dim3(grid1), dim3(512), kC3wLds, stream, static_cast<const float*>(scratch),
+            hipLaunchKernelGGL(cnn3w_kernel<false>, dim3(grid1), dim3(512), kC3wLds, stream, static_cast<const float*>(scratch),
                                static_cast<const float*>(apw), int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_hw),
-                               packed + L.conv3_hws, packed + L.conv3_b, pooled);
+                               packed + L.conv3_hws, packed + L.conv3_b, pooled, static_cast<uint16_t*>(nullptr));
             WW_HIP(hipGetLastError());
             return WW_OK;
         }

@@ -141,7 +141,9 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
 
 int train_math_mode();   // 0 exact fp32, 1 split-precision conv backward where a kernel exists (ww_train_h.hip)
 int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st);
-int launch_pack_conv_h_dev(const float* w1, const float* b1, const float* w2, const float* b2, float* img, hipStream_t st);
+int launch_pack_conv_h_dev(const ww_train_params* p, float* img, hipStream_t st);
+int launch_cnn3w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* mid2, float* apow2, float* pooled,
+                           uint32_t* bits3, uint32_t* bits1, hipStream_t stream);
 int launch_cnn2w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* pooled, uint32_t* bits, uint32_t* bits1,
                            hipStream_t stream);
 int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float* gp, int64_t n, int width, const float* packed,

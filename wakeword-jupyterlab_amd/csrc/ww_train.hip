@@ -107,7 +107,8 @@ struct WgradCfg {
     static_assert(BAND % kSplits == 0 && kLdsFloats * 4 <= 160 * 1024, "band does not fit");
 };
 
-template <int CIN, int COUT, int BAND, bool DENSE, bool FROM_MEL>
+// BITS (split-precision forward): the mask arrives as bits [b][row][col][COUT bits] and iact as [b][row][col][CIN] (channels last).
+template <int CIN, int COUT, int BAND, bool DENSE, bool FROM_MEL, bool BITS = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const float* __restrict__ mel, const float* __restrict__ iact,
                                                             const float* __restrict__ oact_or_dz, const float* __restrict__ gp /*[n][COUT]*/,
                                                             int n, int width, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -161,7 +162,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
                 for (int p = 0; p < kGmPasses; ++p) {
                     const int co = lrow8 + 64 * p;
-                    const float4 v = *reinterpret_cast<const float4*>(oact_or_dz + ((int64_t(clip) * kTH + y0 + r) * COUT + co) * kTW + lcol);
+                    float4 v;
+                    if constexpr (BITS) {
+                        const uint8_t* mb = reinterpret_cast<const uint8_t*>(oact_or_dz) + ((int64_t(clip) * kTH + y0 + r) * kTW + lcol) * (COUT / 8) + (co >> 3);
+                        const int sh = co & 7;
+                        v = make_float4(float((mb[0] >> sh) & 1), float((mb[COUT / 8] >> sh) & 1), float((mb[2 * (COUT / 8)] >> sh) & 1),
+                                        float((mb[3 * (COUT / 8)] >> sh) & 1));
+                    } else {
+                        v = *reinterpret_cast<const float4*>(oact_or_dz + ((int64_t(clip) * kTH + y0 + r) * COUT + co) * kTW + lcol);
+                    }
                     float* d = gm + (r * COUT + co) * 33 + lcol;
                     float g0, g1, g2, g3;
                     if constexpr (DENSE) { g0 = v.x; g1 = v.y; g2 = v.z; g3 = v.w; }
@@ -191,13 +200,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const float* __restr
 #pragma unroll 1
                 for (int q = 0; q < BAND + 2; ++q) {
                     const int y = y0 - 1 + q;
-#pragma unroll
-                    for (int p = 0; p < CIN / 64; ++p) {
-                        const int ci = lrow8 + 64 * p;
+                    if constexpr (BITS) {      // channels last: thread = (column, 4 channels), 16 lanes cover one position's 256 bytes
+                        static_assert(CIN == 64, "512 threads = 32 columns x 16 groups of 4 channels");
+                        const int col = tid >> 4, c4 = (tid & 15) * 4;
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (y >= 0 && y < kTH) v = *reinterpret_cast<const float4*>(iact + ((int64_t(clip) * kTH + y) * CIN + ci) * kTW + lcol);
-                        float* d = act + ci * Cfg::kActCi + q * kTRS + lcol + 1;
-                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        if (y >= 0 && y < kTH) v = *reinterpret_cast<const float4*>(iact + ((int64_t(clip) * kTH + y) * kTW + col) * CIN + c4);
+                        float* d = act + c4 * Cfg::kActCi + q * kTRS + col + 1;
+                        d[0] = v.x; d[Cfg::kActCi] = v.y; d[2 * Cfg::kActCi] = v.z; d[3 * Cfg::kActCi] = v.w;
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < CIN / 64; ++p) {
+                            const int ci = lrow8 + 64 * p;
+                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (y >= 0 && y < kTH) v = *reinterpret_cast<const float4*>(iact + ((int64_t(clip) * kTH + y) * CIN + ci) * kTW + lcol);
+                            float* d = act + ci * Cfg::kActCi + q * kTRS + lcol + 1;
+                            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        }
                     }
                 }
             }
@@ -401,7 +419,13 @@ __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dg
                         const int64_t at = ((int64_t(clip) * kTH + y) * CIN + 32 * nt + ln) * kTW + 4 * h;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
-                            const float4 ia = *reinterpret_cast<const float4*>(iact + at + 8 * gq);
+                            float4 ia;
+                            if constexpr (BITS) {  // relu(conv2) channels last [b][row][col][CIN]: columns 4h + 8gq .. +3 of channel 32 nt + ln
+                                const float* ip = iact + ((int64_t(clip) * kTH + y) * kTW + 4 * h + 8 * gq) * CIN + 32 * nt + ln;
+                                ia = make_float4(ip[0], ip[CIN], ip[2 * CIN], ip[3 * CIN]);
+                            } else {
+                                ia = *reinterpret_cast<const float4*>(iact + at + 8 * gq);
+                            }
                             float4 dz;
                             dz.x = ia.x > 0.f ? acc[r][4 * gq + 0] : 0.f;
                             dz.y = ia.y > 0.f ? acc[r][4 * gq + 1] : 0.f;
@@ -574,9 +598,10 @@ struct TrainWs {
     float *mid2, *mid3, *dz2, *pooled, *gates0, *mask0, *hd0, *gates1, *mask1, *hd1, *lstm_packed, *conv2_b_op, *conv3_b_op, *dgrad2_b_op, *dgrad3_b_op;
     float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *partial, *reduced;
     uint32_t* maskbits;                                  // [n][80][32][c_last / 32]: [relu(last conv) > 0]
-    float* wpk;                                          // 2-conv model, split precision: packed image written on the device
-    uint32_t* bits1;                                     // 2-conv model, split precision: [n][80][32] sign bits of conv1
+    float* wpk;                                          // split precision: packed image written on the device
+    uint32_t* bits1;                                     // split precision: [n][80][32] sign bits of conv1
     float* dgh;                                          // scratch of the split-precision data-gradient kernel
+    float* apow2;                                        // 3-conv model, split precision: 2^a2 per clip (cnn2w_kernel<3> -> cnn3w_kernel)
     int64_t total;
 };
 static int64_t a256(int64_t floats) { return (floats * 4 + 255) / 256 * 64; }      // floats, 256-byte granules
@@ -602,8 +627,9 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     w.partial = take(int64_t(kMaxGroups) * (n_conv == 3 ? kWg3Partial : kWg2Partial));      // reused by every partial-producing kernel in turn
     w.reduced = take(n_conv == 3 ? kWg3Partial : kWg2Partial);
     w.maskbits = reinterpret_cast<uint32_t*>(take(n * kTH * kTW * (c_last / 32)));
-    w.wpk = n_conv == 2 ? take(packed_layout(2).total) : nullptr;
-    w.bits1 = n_conv == 2 ? reinterpret_cast<uint32_t*>(take(n * kTH * kTW)) : nullptr;
+    w.wpk = take(packed_layout(n_conv).total);
+    w.bits1 = reinterpret_cast<uint32_t*>(take(n * kTH * kTW));
+    w.apow2 = n_conv == 3 ? take(n) : nullptr;
     w.dgh = n_conv == 2 ? take(dgrad_h_scratch_floats(n)) : nullptr;
     w.total = o * 4;
     return w;
@@ -627,6 +653,8 @@ static int train_opt_in() {
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, false, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false>), DgradCfg<64, 128>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false, true>), DgradCfg<64, 128>::kLdsFloats));
+    WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<64, 128, 4, false, false, true>), WgradCfg<64, 128, 4>::kLdsFloats));
     done[dev] = true;
     return WW_OK;
 }
@@ -641,9 +669,8 @@ int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, floa
 
 // test / diagnostic: the packed image the last split-precision forward of the 2-conv model wrote on the device
 int train_packed_image(const void* workspace, int64_t n, int n_conv, float* img, hipStream_t st) {
-    if (n_conv != 2) return fail(WW_EUNSUPPORTED, "the device-packed image exists for the 2-conv model only");
     TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv);
-    WW_HIP(hipMemcpyAsync(img, w.wpk, sizeof(float) * packed_layout(2).total, hipMemcpyDeviceToDevice, st));
+    WW_HIP(hipMemcpyAsync(img, w.wpk, sizeof(float) * packed_layout(n_conv).total, hipMemcpyDeviceToDevice, st));
     return WW_OK;
 }
 
@@ -652,12 +679,17 @@ int train_forward(const float* mel, int64_t n, int width, const ww_train_params*
     if (device_cu_count() > kMaxGroups) return fail(WW_EUNSUPPORTED, "more than 256 CUs: the workspace is sized for 256 partials");
     const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
     TrainWs w = carve_train(workspace, n, nc);
-    if (train_math_mode() == WW_TRAIN_MATH_F16X3 && nc == 2) {
-        // split precision: the inference kernel (conv2 as 1-D Winograd on the f16 matrix cores) with the ReLU mask as a second output;
-        // relu(conv2) itself is never stored.  The backward pass must run under the same arithmetic (it reads the mask bits).
-        WW_HIP(hipMemsetAsync(w.wpk, 0, sizeof(float) * packed_layout(2).total, st));
-        if (int rc = launch_pack_conv_h_dev(p->conv_weight[0], p->conv_bias[0], p->conv_weight[1], p->conv_bias[1], w.wpk, st)) return rc;
-        if (int rc = launch_cnn2w_pool_bits(mel, n, width, w.wpk, w.pooled, w.maskbits, w.bits1, st)) return rc;
+    if (train_math_mode() == WW_TRAIN_MATH_F16X3) {
+        // split precision: the inference kernels (convs as 1-D Winograd on the f16 matrix cores) with the ReLU masks as extra outputs.
+        // 2 convs: relu(conv2) itself is never stored.  3 convs: relu(conv2) stays as float32 [row][column][64].
+        // The backward pass must run under the same arithmetic (it reads the bit images).
+        WW_HIP(hipMemsetAsync(w.wpk, 0, sizeof(float) * packed_layout(nc).total, st));
+        if (int rc = launch_pack_conv_h_dev(p, w.wpk, st)) return rc;
+        if (nc == 2) {
+            if (int rc = launch_cnn2w_pool_bits(mel, n, width, w.wpk, w.pooled, w.maskbits, w.bits1, st)) return rc;
+        } else {
+            if (int rc = launch_cnn3w_pool_bits(mel, n, width, w.wpk, w.mid2, w.apow2, w.pooled, w.maskbits, w.bits1, st)) return rc;
+        }
         return launch_lstm_fc_train(w.pooled, n, c_last, p->lstm_weight_ih[0], p->lstm_bias_ih[0], p->lstm_bias_hh[0], p->lstm_weight_ih[1],
                                     p->lstm_bias_ih[1], p->lstm_bias_hh[1], p->fc_weight, p->fc_bias, w.lstm_packed, w.gates0, w.mask0, w.hd0,
                                     w.gates1, w.mask1, w.hd1, p_lstm, p_fc, seed, logits, st);
@@ -695,7 +727,8 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const int grid = int(n < cus ? n : cus);         // one persistent workgroup per CU (117-149 KB of LDS each)
     TrainWs w = carve_train(workspace, n, nc);
     const int N = int(n), H = kHidden;
-    const bool split = train_math_mode() == WW_TRAIN_MATH_F16X3 && nc == 2;      // the kernels of ww_train_h.hip
+    const bool bits = train_math_mode() == WW_TRAIN_MATH_F16X3;       // the forward left bit images (and channels-last relu(conv2))
+    const bool split = bits && nc == 2;                               // the kernels of ww_train_h.hip
     // fc: dW = dlogits^T hd1, db = colsum(dlogits), dhd1 = dlogits W_fc
     sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st);
     hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, st, dlogits, N, 2, g->fc_bias);
@@ -721,12 +754,20 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const float* b1 = p->conv_bias[0];
     if (nc == 3) {
         hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(288), dim3(256), 0, st, p->conv_weight[2], 128, 64, w.dgrad3_b_op);
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, false, false>), dim3(grid), dim3(512), kWg3Lds, st,
-                           mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.partial);
+        if (bits)
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, false, false, true>), dim3(grid), dim3(512), kWg3Lds, st,
+                               mel, w.mid2, reinterpret_cast<const float*>(w.maskbits), w.gp, N, width, w1, b1, w.partial);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, false, false>), dim3(grid), dim3(512), kWg3Lds, st,
+                               mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.partial);
         WW_HIP(hipGetLastError());
         if (int rc = reduce_to(w, grid, kWg3Partial, 128 * 64 * 9, g->conv_weight[2], g->conv_bias[2], 128, st)) return rc;
-        hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false>), dim3(grid), dim3(512), kDg3Lds, st,
-                           mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
+        if (bits)
+            hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false, true>), dim3(grid), dim3(512), kDg3Lds, st,
+                               mel, w.mid2, reinterpret_cast<const float*>(w.maskbits), w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
+        else
+            hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false>), dim3(grid), dim3(512), kDg3Lds, st,
+                               mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
         WW_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], 64, 32, w.dgrad2_b_op);

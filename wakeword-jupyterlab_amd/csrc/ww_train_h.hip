@@ -108,50 +108,64 @@ __global__ __launch_bounds__(256) void pack_conv1_h_dev_kernel(const float* __re
     }
 }
 
-// one workgroup of 128 threads per output channel co (thread = (ci, dx) for 96 of them): U0 = w[dy=0], U1 = (w0+w1+w2)/2,
-// U2 = (w0-w1+w2)/2, U3 = w[dy=2] in double; the channel's exponent from max |U|; operand order [nt][ks = xi*3+dx][hi,lo][lane][8]
-__global__ __launch_bounds__(128) void pack_conv2_wino_dev_kernel(const float* __restrict__ w2, float* __restrict__ img, PackOffsets o) {
-    __shared__ double red[128];
+// one workgroup per output channel co, thread = (ci, dx): U0 = w[dy=0], U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w[dy=2] in double;
+// the channel's exponent from max |U|; operand order [nt][ks = (xi*3+dx)*(CIN/32) + cb][hi,lo][lane][8] (pack_conv_wino_f16x3).
+// range_at >= 0 (conv2): the row's l1 norm feeds img[range_at] through an atomic max.
+template <int CIN>
+__global__ __launch_bounds__(CIN * 4) void pack_conv_wino_dev_kernel(const float* __restrict__ w, float* __restrict__ img, int64_t at_hw,
+                                                                      int64_t at_hws, int64_t range_at) {
+    constexpr int T = CIN * 4, NCB = CIN / 32;
+    __shared__ double red[T];
     const int co = blockIdx.x, tid = threadIdx.x;
     const int ci = tid / 3, dx = tid - 3 * ci;
     double u[4] = {0., 0., 0., 0.};
-    if (tid < 96) {
-        const double w0 = w2[((co * 32 + ci) * 3 + 0) * 3 + dx], w1v = w2[((co * 32 + ci) * 3 + 1) * 3 + dx], w2v = w2[((co * 32 + ci) * 3 + 2) * 3 + dx];
+    if (tid < CIN * 3) {
+        const double w0 = w[((co * CIN + ci) * 3 + 0) * 3 + dx], w1v = w[((co * CIN + ci) * 3 + 1) * 3 + dx], w2v = w[((co * CIN + ci) * 3 + 2) * 3 + dx];
         u[0] = w0; u[1] = 0.5 * (w0 + w1v + w2v); u[2] = 0.5 * (w0 - w1v + w2v); u[3] = w2v;
     }
     red[tid] = fmax(fmax(fabs(u[0]), fabs(u[1])), fmax(fabs(u[2]), fabs(u[3])));
     __syncthreads();
-    for (int off = 64; off > 0; off >>= 1) {
+    for (int off = T / 2; off > 0; off >>= 1) {
         if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
         __syncthreads();
     }
     const int S = scale_exp_dev(float(red[0]) * 1.0000001f);
     if (tid == 0) {                              // the row's l1 norm summed in the host's order by one thread
-        img[o.conv2_hws + co] = ldexpf(1.0f, -S);
-        double s = 0.0;
-        for (int i = 0; i < 32 * 9; ++i) s += fabs(double(w2[co * 288 + i]));
-        atomicMax(reinterpret_cast<unsigned int*>(img + o.range + 2), __float_as_uint(float(s * (1.0 + 1e-6))));
+        img[at_hws + co] = ldexpf(1.0f, -S);
+        if (range_at >= 0) {
+            double s = 0.0;
+            for (int i = 0; i < CIN * 9; ++i) s += fabs(double(w[co * CIN * 9 + i]));
+            atomicMax(reinterpret_cast<unsigned int*>(img + range_at), __float_as_uint(float(s * (1.0 + 1e-6))));
+        }
     }
-    if (tid < 96) {
-        uint16_t* o16 = reinterpret_cast<uint16_t*>(img + o.conv2_hw);
-        const int nt = co >> 4, lane = (co & 15) + 16 * ((ci & 31) >> 3), j = ci & 7;
+    if (tid < CIN * 3) {
+        uint16_t* o16 = reinterpret_cast<uint16_t*>(img + at_hw);
+        const int nt = co >> 4, cb = ci >> 5, lane = (co & 15) + 16 * ((ci & 31) >> 3), j = ci & 7;
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
-            const int ks = xi * 3 + dx;
+            const int ks = (xi * 3 + dx) * NCB + cb;
             uint16_t hb, lb;
             split_f16_dev(ldexp(u[xi], S), hb, lb);
-            const int64_t base = ((int64_t(nt) * 12 + ks) * 2) * 64 * 8;
+            const int64_t base = ((int64_t(nt) * 12 * NCB + ks) * 2) * 64 * 8;
             o16[base + lane * 8 + j] = hb;
             o16[base + 64 * 8 + lane * 8 + j] = lb;
         }
     }
 }
+__global__ void copy_floats_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
 
-int launch_pack_conv_h_dev(const float* w1, const float* b1, const float* w2, const float* b2, float* img, hipStream_t st) {
-    const PackedLayout L = packed_layout(2);
+// n_conv 2: conv1 + conv2 (Winograd) + range;  n_conv 3: also conv3 (Winograd) and its bias
+int launch_pack_conv_h_dev(const ww_train_params* p, float* img, hipStream_t st) {
+    const PackedLayout L = packed_layout(p->n_conv);
     const PackOffsets o{L.conv1_h, L.conv1_hs, L.conv1_b, L.conv2_hw, L.conv2_hws, L.conv2_b, L.range};
-    hipLaunchKernelGGL(pack_conv1_h_dev_kernel, dim3(1), dim3(256), 0, st, w1, b1, b2, img, o);
-    hipLaunchKernelGGL(pack_conv2_wino_dev_kernel, dim3(64), dim3(128), 0, st, w2, img, o);
+    hipLaunchKernelGGL(pack_conv1_h_dev_kernel, dim3(1), dim3(256), 0, st, p->conv_weight[0], p->conv_bias[0], p->conv_bias[1], img, o);
+    hipLaunchKernelGGL(pack_conv_wino_dev_kernel<32>, dim3(64), dim3(128), 0, st, p->conv_weight[1], img, L.conv2_hw, L.conv2_hws, L.range + 2);
+    if (p->n_conv == 3) {
+        hipLaunchKernelGGL(pack_conv_wino_dev_kernel<64>, dim3(128), dim3(256), 0, st, p->conv_weight[2], img, L.conv3_hw, L.conv3_hws, int64_t(-1));
+        hipLaunchKernelGGL(copy_floats_kernel, dim3(1), dim3(128), 0, st, p->conv_bias[2], img + L.conv3_b, 128);
+    }
     WW_HIP(hipGetLastError());
     return WW_OK;
 }

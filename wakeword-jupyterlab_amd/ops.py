@@ -330,7 +330,7 @@ def train_last_masks(n: int):
 def train_last_packed_image() -> torch.Tensor:
     """Diagnostic: the packed image the most recent split-precision training forward of the 2-conv model wrote on the device."""
     ws = _TrainStep.last_workspace
-    img = torch.empty(int(nat.lib.ww_packed_weights_floats(2)), device=ws.device, dtype=torch.float32)
+    img = torch.empty(int(nat.lib.ww_packed_weights_floats(_TrainStep.last_n_conv)), device=ws.device, dtype=torch.float32)
     with torch.cuda.device(ws.device):
         nat.check(nat.lib.ww_train_packed_image(_ptr(ws), _TrainStep.last_n, _TrainStep.last_n_conv, _ptr(img), _stream()))
     return img
