@@ -654,7 +654,6 @@ static int train_opt_in() {
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false>), DgradCfg<64, 128>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false, true>), DgradCfg<64, 128>::kLdsFloats));
-    WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<64, 128, 4, false, false, true>), WgradCfg<64, 128, 4>::kLdsFloats));
     done[dev] = true;
     return WW_OK;
 }
@@ -754,14 +753,16 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const float* b1 = p->conv_bias[0];
     if (nc == 3) {
         hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(288), dim3(256), 0, st, p->conv_weight[2], 128, 64, w.dgrad3_b_op);
-        if (bits)
-            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, false, false, true>), dim3(grid), dim3(512), kWg3Lds, st,
-                               mel, w.mid2, reinterpret_cast<const float*>(w.maskbits), w.gp, N, width, w1, b1, w.partial);
-        else
+        if (bits) {
+            if (int rc = launch_conv3_wgrad_h(w.mid2, w.apow2, w.maskbits, w.gp, n, w.partial, w.reduced, grid, st)) return rc;
+            WW_HIP(hipMemcpyAsync(g->conv_weight[2], w.reduced, sizeof(float) * 128 * 64 * 9, hipMemcpyDeviceToDevice, st));
+            WW_HIP(hipMemcpyAsync(g->conv_bias[2], w.reduced + 128 * 64 * 9, sizeof(float) * 128, hipMemcpyDeviceToDevice, st));
+        } else {
             hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, false, false>), dim3(grid), dim3(512), kWg3Lds, st,
                                mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.partial);
-        WW_HIP(hipGetLastError());
-        if (int rc = reduce_to(w, grid, kWg3Partial, 128 * 64 * 9, g->conv_weight[2], g->conv_bias[2], 128, st)) return rc;
+            WW_HIP(hipGetLastError());
+            if (int rc = reduce_to(w, grid, kWg3Partial, 128 * 64 * 9, g->conv_weight[2], g->conv_bias[2], 128, st)) return rc;
+        }
         if (bits)
             hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false, true>), dim3(grid), dim3(512), kDg3Lds, st,
                                mel, w.mid2, reinterpret_cast<const float*>(w.maskbits), w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);

@@ -463,6 +463,218 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient of conv3 (64 -> 128) of the 3-conv WakewordModel: the conv2 kernel's arithmetic (mask x hi/lo, transposed reads) with
+//   * the B operand = relu(conv2) from HBM (float32 channels last, written by the forward) scaled by the clip's 2^-a2 and split by the
+//     producers (thread = column x 8 channels: two 16-byte loads, two 16-byte stores per row);
+//   * the 128 co in two PASSES of 64 per clip (a pass = the conv2 kernel's clip: 20 steps; mask records hold the pass's 64 channels), so
+//     that a consumer wave = (16 co) x (2 x 16 ci) keeps 18 accumulators (72 VGPRs) and the kernel its 12 waves at 3 per SIMD;
+//   * dW accumulated in the workgroup's own partial in GLOBAL memory, in accumulator (lane) order: after every pass
+//     partial[pass][wave][pair*9 + tap][j][lane] += gp[b,co] 2^a2 S  (72 coalesced read-modify-writes per wave and pass; no atomics: the
+//     region is private to the wave), un-permuted by reduce_wgrad3_h_kernel.
+// ------------------------------------------------------------------------------------------------
+struct Wg3H {
+    static constexpr int CIN = 64, COUT = 128;
+    static constexpr int kARec = CIN * 4 + 16, kGRec = 64 * 2 + 16;        // 272, 144 bytes (mask records: the pass's 64 co)
+    static constexpr int kARow = 34 * kARec, kGRow = 32 * kGRec;
+    static constexpr int kOffA = kHGRing * kGRow;
+    static constexpr int kOffLut = kOffA + 2 * kHRows * kARow;
+    static constexpr int kLds = kOffLut + 256 * 16;
+    static constexpr int kPartial = COUT * CIN * 9 + COUT;                   // = conv_wgrad_kernel<64, 128>'s partial
+};
+static_assert(Wg3H::kLds <= 160 * 1024 && Wg3H::kOffA % 16 == 0 && Wg3H::kOffLut % 16 == 0, "LDS map");
+
+__global__ __launch_bounds__(768, 3) void conv3_wgrad_h_kernel(const float* __restrict__ act2 /*[n][80][32][64]*/, const float* __restrict__ apow2,
+                                                               const uint8_t* __restrict__ maskbits /*[n][80][32][16 bytes]*/,
+                                                               const float* __restrict__ gp /*[n][128]*/, int n, float* __restrict__ partial) {
+    using L = Wg3H;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* gring = ldsb;
+    char* aring = ldsb + L::kOffA;
+    u32x4* lut = reinterpret_cast<u32x4*>(ldsb + L::kOffLut);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 8;
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int total = my_clips * 2 * kHSteps;                     // global step gs = (clip k, pass hf, step s) = ((k*2 + hf)*20 + s)
+
+    for (int i = tid; i < L::kLds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;    // halo columns stay zero
+    __syncthreads();
+    if (tid < 256) {
+        u32x4 m;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) m[d] = ((tid >> (2 * d)) & 1 ? 0x3c00u : 0u) | ((tid >> (2 * d + 1)) & 1 ? 0x3c000000u : 0u);
+        lut[tid] = m;
+    }
+    __syncthreads();
+    float* mypart = partial + int64_t(blockIdx.x) * L::kPartial;
+
+    if (!consumer) {
+    // ================================================= producers =================================================
+    const int ptid = tid - 512;
+    const int mcol = ptid >> 3, mcg = ptid & 7;                  // column, byte of the pass's 64 mask bits / group of 8 input channels
+    auto produce = [&](int gs) {
+        const int vc = gs / kHSteps, s = gs - vc * kHSteps;        // vc = k*2 + hf: a pass is this kernel's "clip"
+        const int k = vc >> 1, hf = vc & 1;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const int g0 = s == 0 ? 0 : 4 * s + 1, g1 = 4 * s + 4 < kTH ? 4 * s + 4 : kTH - 1;
+        uint8_t mb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int g = g0 + i;
+            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mcol) * 16 + 8 * hf + mcg] : uint8_t(0);
+        }
+        // relu(conv2) rows 4s .. 4s+3, this thread's column and 8 channels
+        const float down = __uint_as_float(0x7f000000u - __float_as_uint(apow2[clip]));       // 2^-a2
+        const float* src = act2 + ((clip * kTH + kHRows * s) * kTW + mcol) * L::CIN + 8 * mcg;
+        float4 va[kHRows], vb[kHRows];
+#pragma unroll
+        for (int i = 0; i < kHRows; ++i) {
+            va[i] = *reinterpret_cast<const float4*>(src + int64_t(i) * kTW * L::CIN);
+            vb[i] = *reinterpret_cast<const float4*>(src + int64_t(i) * kTW * L::CIN + 4);
+        }
+        char* arow = aring + ((gs & 1) * kHRows) * L::kARow + (mcol + 1) * L::kARec + mcg * 16;
+#pragma unroll
+        for (int i = 0; i < kHRows; ++i) {
+            u32x4 vh, vl;
+            uint32_t hh, ll;
+            split2(va[i].x * down, va[i].y * down, hh, ll); vh[0] = hh; vl[0] = ll;
+            split2(va[i].z * down, va[i].w * down, hh, ll); vh[1] = hh; vl[1] = ll;
+            split2(vb[i].x * down, vb[i].y * down, hh, ll); vh[2] = hh; vl[2] = ll;
+            split2(vb[i].z * down, vb[i].w * down, hh, ll); vh[3] = hh; vl[3] = ll;
+            *reinterpret_cast<u32x4*>(arow + i * L::kARow) = vh;
+            *reinterpret_cast<u32x4*>(arow + i * L::kARow + L::CIN * 2) = vl;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int g = g0 + i;
+            if (g <= g1) {
+                const int slot = (vc * kTH + g) % kHGRing;
+                *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + mcol * L::kGRec + mcg * 16) = lut[mb[i]];
+            }
+        }
+    };
+    if (total > 0) produce(0);
+    __syncthreads();
+    for (int gs = 0; gs < total; ++gs) {
+        if (gs + 1 < total) produce(gs + 1);
+        __syncthreads();
+    }
+    } else {
+    // ================================================= consumers =================================================
+    const int ct = wave & 3, ip = (wave >> 2) & 1;                 // 16 co of the pass x ci tiles 2 ip, 2 ip + 1
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, ln = lane & 15;
+    const char* abase = gring + (8 * grp + 2 * q) * L::kGRec + (16 * ct + 4 * p) * 2;
+    const char* bbase = aring + (8 * grp + 2 * q) * L::kARec + (32 * ip + 4 * p) * 2;
+    f32x4 S[2][9], cnt;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[u][t][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cnt[j] = 0.f;
+    half8 a_prev, a_cur, a_next, ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a_prev[j] = 0; a_cur[j] = 0; a_next[j] = 0; ones[j] = static_cast<_Float16>(1.0f); }
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float up = 0.f;
+    auto load_a = [&](int vc, int g) -> half8 {
+        const char* r = abase + ((vc * kTH + g) % kHGRing) * L::kGRow;
+        return cat8(lds_tr16(r), lds_tr16(r + L::kGRec));
+    };
+    __syncthreads();
+    for (int gs = 0; gs < total; ++gs) {
+        const int vc = gs / kHSteps, s = gs - vc * kHSteps;
+        const int k = vc >> 1, hf = vc & 1;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        if (s == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a_prev[j] = 0;
+            a_cur = load_a(vc, 0);
+            g4 = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 64 * hf + 16 * ct + 4 * grp);
+            up = apow2[clip];
+        }
+#pragma unroll
+        for (int i = 0; i < kHRows; ++i) {
+            const int r = kHRows * s + i;
+            if (r + 1 < kTH) a_next = load_a(vc, r + 1);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a_next[j] = 0;
+            }
+            const char* br = bbase + ((gs & 1) * kHRows + i) * L::kARow;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                half8 bh[3], bl[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const char* b0 = br + dx * L::kARec + u * 32;
+                    bh[dx] = cat8(lds_tr16(b0), lds_tr16(b0 + L::kARec));
+                    bl[dx] = cat8(lds_tr16(b0 + L::CIN * 2), lds_tr16(b0 + L::kARec + L::CIN * 2));
+                }
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const half8 ay = dy == 0 ? a_next : (dy == 1 ? a_cur : a_prev);       // mask row r - dy + 1
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        S[u][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay, bh[dx], S[u][dy * 3 + dx], 0, 0, 0);
+                        S[u][dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay, bl[dx], S[u][dy * 3 + dx], 0, 0, 0);
+                    }
+                }
+            }
+            cnt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, ones, cnt, 0, 0, 0);
+            a_prev = a_cur;
+            a_cur = a_next;
+        }
+        if (s == kHSteps - 1) {
+            // partial += gp[b, co] * 2^a2 * S; D register j <-> co = 64 hf + 16 ct + 4 grp + j, lane & 15 <-> ci = 16 (2 ip + u) + ln
+            const float gj[4] = {g4.x, g4.y, g4.z, g4.w};
+            float* pp = mypart + ((hf * 8 + wave) * 18) * 256 + lane;
+            const bool first = k == 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* at = pp + ((u * 9 + t) * 4 + j) * 64;
+                        const float v = gj[j] * (S[u][t][j] * up);
+                        *at = first ? v : *at + v;
+                        S[u][t][j] = 0.f;
+                    }
+            if (ip == 0 && ln == 0) {
+                float* db = mypart + L::COUT * L::CIN * 9 + 64 * hf + 16 * ct + 4 * grp;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) db[j] = first ? gj[j] * cnt[j] : db[j] + gj[j] * cnt[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cnt[j] = 0.f;
+        }
+        __syncthreads();
+    }
+    }
+}
+
+// sum of the workgroups' lane-order partials in a fixed order, un-permuted to torch's [128][64][3][3] (+ bias)
+__global__ void reduce_wgrad3_h_kernel(const float* __restrict__ partial, int groups, float* __restrict__ out) {
+    constexpr int kW = 128 * 64 * 9, kP = kW + 128;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kP; i += gridDim.x * blockDim.x) {
+        int src = i;
+        if (i < kW) {
+            const int t = i % 9, ci = (i / 9) % 64, co = i / (9 * 64);
+            const int hf = co >> 6, ct = (co >> 4) & 3, grp = (co >> 2) & 3, j = co & 3, it = ci >> 4, ln = ci & 15;
+            const int wave = ct + 4 * (it >> 1), u = it & 1;
+            src = ((((hf * 8 + wave) * 18) + u * 9 + t) * 4 + j) * 64 + ln + 16 * grp;
+        }
+        float sum = 0.f;
+        for (int g = 0; g < groups; ++g) sum += partial[int64_t(g) * kP + src];
+        out[i] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Data gradient of conv2 and, from it, the weight gradient of conv1 -- the first layer: da1 is consumed where it is produced.
 //   da1[ci][y][x] = sum_{co,dy,dx} mask2[co][y-dy+1][x-dx+1] * G[co][ci][dy][dx],     G = gp[b,co] * W2   (rebuilt per clip)
 //   D[m = column][n = ci] += A[m][k] B[k][n] on v_mfma_f32_16x16x32_f16, k = 32 of the 64 co of one tap:
@@ -698,6 +910,7 @@ static int train_h_opt_in() {
     if (done[dev]) return WW_OK;
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WgH::kLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DgH::kLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wg3H::kLds));
     done[dev] = true;
     return WW_OK;
 }
@@ -715,6 +928,17 @@ int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float
     hipLaunchKernelGGL(conv2_wgrad_h_kernel, dim3(grid), dim3(768), WgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), gp, int(n),
                        width, reinterpret_cast<const u32x4*>(packed + P.conv1_h), packed + P.conv1_hs, packed + P.conv1_b, packed + P.range,
                        partial);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// conv3 weight gradient of the 3-conv model: partial [grid][128*64*9 + 128] (lane order) -> reduced [128*64*9 + 128] in torch order
+int launch_conv3_wgrad_h(const float* act2, const float* apow2, const uint32_t* maskbits, const float* gp, int64_t n, float* partial,
+                         float* reduced, int grid, hipStream_t st) {
+    if (int rc = train_h_opt_in()) return rc;
+    hipLaunchKernelGGL(conv3_wgrad_h_kernel, dim3(grid), dim3(768), Wg3H::kLds, st, act2, apow2, reinterpret_cast<const uint8_t*>(maskbits), gp,
+                       int(n), partial);
+    hipLaunchKernelGGL(reduce_wgrad3_h_kernel, dim3(288), dim3(256), 0, st, partial, grid, reduced);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
