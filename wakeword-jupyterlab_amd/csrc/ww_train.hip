@@ -630,7 +630,7 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     w.wpk = take(packed_layout(n_conv).total);
     w.bits1 = reinterpret_cast<uint32_t*>(take(n * kTH * kTW));
     w.apow2 = n_conv == 3 ? take(n) : nullptr;
-    w.dgh = n_conv == 2 ? take(dgrad_h_scratch_floats(n)) : nullptr;
+    w.dgh = take(dgrad_h_scratch_floats(n, n_conv));
     w.total = o * 4;
     return w;
 }
@@ -653,7 +653,6 @@ static int train_opt_in() {
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, false, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false>), DgradCfg<64, 128>::kLdsFloats));
-    WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false, true>), DgradCfg<64, 128>::kLdsFloats));
     done[dev] = true;
     return WW_OK;
 }
@@ -742,8 +741,8 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     sgemm(w.dg0, 1, 4 * H, w.pooled, c_last, 1, g->lstm_weight_ih[0], c_last, 4 * H, c_last, N, st);       // [1024][C] = dg0^T pooled
     hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(1024), 0, st, w.dg0, N, 4 * H, g->lstm_bias[0]);
     sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], c_last, 1, w.dpooled, c_last, N, c_last, 4 * H, st);      // [n][C] = dg0 W_ih_l0
-    if (split) {
-        if (int rc = launch_gp_max(w.dpooled, 1.0f / float(kTH * width), n, w.gp, w.dgh, st)) return rc;
+    if (bits) {
+        if (int rc = launch_gp_max(w.dpooled, 1.0f / float(kTH * width), n, nc, w.gp, w.dgh, st)) return rc;
     } else {
         hipLaunchKernelGGL(scale_kernel, dim3(256), dim3(256), 0, st, w.dpooled, 1.0f / float(kTH * width), n * c_last, w.gp);
         WW_HIP(hipGetLastError());
@@ -763,10 +762,9 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
             WW_HIP(hipGetLastError());
             if (int rc = reduce_to(w, grid, kWg3Partial, 128 * 64 * 9, g->conv_weight[2], g->conv_bias[2], 128, st)) return rc;
         }
-        if (bits)
-            hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false, true>), dim3(grid), dim3(512), kDg3Lds, st,
-                               mel, w.mid2, reinterpret_cast<const float*>(w.maskbits), w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
-        else
+        if (bits) {
+            if (int rc = launch_conv3_dgrad_h(w.mid2, w.maskbits, w.gp, p->conv_weight[2], w.dgh, n, w.dz2, grid, st)) return rc;
+        } else
             hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false>), dim3(grid), dim3(512), kDg3Lds, st,
                                mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
         WW_HIP(hipGetLastError());

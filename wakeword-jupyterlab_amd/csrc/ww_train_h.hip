@@ -900,6 +900,225 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Data gradient of conv3 (3-conv model):  dz2 = [relu(conv2) > 0] * sum_{co,dy,dx} mask3[co][y-dy+1][x-dx+1] * G[co][ci][dy][dx],
+// G = gp[b,co] * W3 rebuilt per clip (conv2_dgrad_h_kernel's arithmetic: mask exact, G 2^-eg as hi + lo, two MFMAs per block).
+// K = 128 co x 9 taps = 36 k-steps per N-tile of 16 ci: 288 B-operand VGPRs -- split over TWO waves (kh = co half, 144 VGPRs each);
+// 8 waves = (4 N-tiles) x (2 K halves), every wave runs both rows of a two-row step.  The halves meet through LDS: wave kh finishes
+// row 2s + kh -- it parks the partial tile of the OTHER row in the exchange buffer, and after the step's barrier adds its partner's partial
+// of its own row, applies relu(conv2)'s sign (float32 channels last, loaded a step ahead) and stores dz2 as [row][channel][column]
+// (what the exact-fp32 conv2 kernels below take).  Mask ring: 6 rows of 288-byte records (128 channels; conflict-free 16-byte row reads).
+// ------------------------------------------------------------------------------------------------
+constexpr int kH3Rows = 2, kH3Steps = kTH / kH3Rows, kH3Ring = 6;
+struct Dg3H {
+    static constexpr int CIN = 64, COUT = 128;
+    static constexpr int kGRec = 288, kGRow = 34 * kGRec;
+    static constexpr int kOffX = kH3Ring * kGRow;                            // exchange: [2 steps][4 nt][2 kh (writer)][2 mt][4 j][64 lanes] floats
+    static constexpr int kOffLut = kOffX + 2 * 4 * 2 * 2 * 4 * 64 * 4;
+    static constexpr int kLds = kOffLut + 256 * 16;
+};
+static_assert(Dg3H::kLds <= 160 * 1024 && Dg3H::kOffX % 16 == 0 && Dg3H::kOffLut % 16 == 0, "LDS map");
+
+// W3 [128][64][3][3] -> wp[(((nt*2 + kh)*18 + ks)*64 + lane)*8 + j] = W3[64 kh + 32 kb + 8 g + j][16 nt + n][dy][dx], ks = (dy*3+dx)*2 + kb
+__global__ void pack_dgrad3_h_dev_kernel(const float* __restrict__ w3, float* __restrict__ wp, unsigned int* __restrict__ wmax) {
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * 2 * 18 * 64 * 8; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 18, kh = (i / (18 * 512)) & 1, nt = i / (2 * 18 * 512);
+        const int kb = ks & 1, tap = ks >> 1, co = 64 * kh + 32 * kb + 8 * (lane >> 4) + j, ci = 16 * nt + (lane & 15);
+        const float v = w3[(co * 64 + ci) * 9 + tap];
+        wp[i] = v;
+        m = fmaxf(m, __builtin_fabsf(v));
+    }
+    atomicMax(wmax, __float_as_uint(m));
+}
+// gp[b][co] = dpooled[b][co] * s, gpmax[b] = max_co |gp[b][co]|: one wave per clip, 128 channels
+__global__ void gp_max128_kernel(const float* __restrict__ dpooled, float s, int n, float* __restrict__ gp, float* __restrict__ gpmax) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n) return;
+    const float v0 = dpooled[int64_t(b) * 128 + lane] * s, v1 = dpooled[int64_t(b) * 128 + 64 + lane] * s;
+    gp[int64_t(b) * 128 + lane] = v0;
+    gp[int64_t(b) * 128 + 64 + lane] = v1;
+    float m = fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) gpmax[b] = m;
+}
+
+__global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __restrict__ act2 /*[n][80][32][64]*/,
+                                                               const uint8_t* __restrict__ maskbits /*[n][80][32][16 bytes]*/,
+                                                               const float* __restrict__ gp, const float* __restrict__ gpmax,
+                                                               const float* __restrict__ wp, const float* __restrict__ w3max, int n,
+                                                               float* __restrict__ dz2 /*[n][80][64][32]*/) {
+    using L = Dg3H;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* gring = ldsb;
+    float* xch = reinterpret_cast<float*>(ldsb + L::kOffX);
+    u32x4* lut = reinterpret_cast<u32x4*>(ldsb + L::kOffLut);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 3, kh = wave >> 2;                       // 16 ci x co half
+    const int ln = lane & 15, grp = lane >> 4;
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+    const int total = my_clips * kH3Steps;
+
+    for (int i = tid; i < L::kLds / 4; i += 512) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;      // halo columns stay zero
+    __syncthreads();
+    if (tid < 256) {
+        u32x4 m;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) m[d] = ((tid >> (2 * d)) & 1 ? 0x3c00u : 0u) | ((tid >> (2 * d + 1)) & 1 ? 0x3c000000u : 0u);
+        lut[tid] = m;
+    }
+    // mask rows a step needs beyond what is in LDS: rows 0..2 (first step of a clip) or 2s+1, 2s+2; thread = (byte of 16, position + 32 per pass)
+    const int mcg = tid & 15, mpos = tid >> 4;
+    uint8_t mb[3];
+    auto fill_load = [&](int gs) {
+        const int k = gs / kH3Steps, s = gs - k * kH3Steps;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const int g0 = s == 0 ? 0 : 2 * s + 1, g1 = 2 * s + 2 < kTH ? 2 * s + 2 : kTH - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int g = g0 + i;
+            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mpos) * 16 + mcg] : uint8_t(0);
+        }
+    };
+    auto fill_store = [&](int gs) {
+        const int k = gs / kH3Steps, s = gs - k * kH3Steps;
+        const int g0 = s == 0 ? 0 : 2 * s + 1, g1 = 2 * s + 2 < kTH ? 2 * s + 2 : kTH - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int g = g0 + i;
+            if (g <= g1) {
+                const int slot = (k * kTH + g) % kH3Ring;
+                *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + (mpos + 1) * L::kGRec + mcg * 16) = lut[mb[i]];
+            }
+        }
+    };
+
+    half8 bh[18], bl[18];
+    float dscale = 0.f;
+    auto rebuild = [&](int k) {
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        const int eg = clampi(exp_of(gpmax[clip] * w3max[0]) - 12, -100, 100);
+        const float down = pow2i(-eg);
+        dscale = pow2i(eg);
+        float gv[16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const float4 v = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 64 * kh + 32 * kb + 8 * grp + 4 * q4);
+                gv[8 * kb + 4 * q4] = v.x * down; gv[8 * kb + 4 * q4 + 1] = v.y * down; gv[8 * kb + 4 * q4 + 2] = v.z * down; gv[8 * kb + 4 * q4 + 3] = v.w * down;
+            }
+        const float4* w4 = reinterpret_cast<const float4*>(wp) + (int64_t(nt * 2 + kh) * 18 * 64 + lane) * 2;
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            const float4 wa = w4[ks * 128], wb = w4[ks * 128 + 1];
+            const int kb = ks & 1;
+            u32x4 vh, vl;
+            uint32_t hh, ll;
+            split2(wa.x * gv[8 * kb], wa.y * gv[8 * kb + 1], hh, ll); vh[0] = hh; vl[0] = ll;
+            split2(wa.z * gv[8 * kb + 2], wa.w * gv[8 * kb + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+            split2(wb.x * gv[8 * kb + 4], wb.y * gv[8 * kb + 5], hh, ll); vh[2] = hh; vl[2] = ll;
+            split2(wb.z * gv[8 * kb + 6], wb.w * gv[8 * kb + 7], hh, ll); vh[3] = hh; vl[3] = ll;
+            bh[ks] = __builtin_bit_cast(half8, vh);
+            bl[ks] = __builtin_bit_cast(half8, vl);
+        }
+    };
+
+    if (total > 0) fill_load(0);
+    __syncthreads();                                               // the LUT is complete
+    if (total > 0) fill_store(0);
+    __syncthreads();
+    const char* abase = gring + (ln + 1) * L::kGRec + kh * 128 + grp * 16;   // A: row = column ln of the m-tile, this wave's 64 co, 8 per lane group
+    f32x4 keep[2];                                                  // this wave's own partial of the row it finishes (row 2s + kh), per m-tile
+    float a2v[2][4];                                                // relu(conv2) at that row: columns 16 mt + 4 grp + j, channel 16 nt + ln
+    float keep_scale = 0.f;
+    int64_t keep_clip = 0;
+    int keep_y = -1;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { keep[mt][j] = 0.f; a2v[mt][j] = 0.f; }
+    // finish the row parked by the previous step: partner's partial from the exchange buffer `buf`
+    auto finish = [&](int buf) {
+        if (keep_y < 0) return;
+        const float* xp = xch + ((((buf * 4 + nt) * 2 + (kh ^ 1)) * 2) * 4) * 64 + lane;
+        float* out = dz2 + ((keep_clip * kTH + keep_y) * L::CIN + 16 * nt + ln) * kTW + 4 * grp;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float4 v;
+            v.x = a2v[mt][0] > 0.f ? (keep[mt][0] + xp[(mt * 4 + 0) * 64]) * keep_scale : 0.f;
+            v.y = a2v[mt][1] > 0.f ? (keep[mt][1] + xp[(mt * 4 + 1) * 64]) * keep_scale : 0.f;
+            v.z = a2v[mt][2] > 0.f ? (keep[mt][2] + xp[(mt * 4 + 2) * 64]) * keep_scale : 0.f;
+            v.w = a2v[mt][3] > 0.f ? (keep[mt][3] + xp[(mt * 4 + 3) * 64]) * keep_scale : 0.f;
+            *reinterpret_cast<float4*>(out + 16 * mt) = v;
+        }
+    };
+    for (int gs = 0; gs < total; ++gs) {
+        const int k = gs / kH3Steps, s = gs - k * kH3Steps;
+        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        finish((gs + 1) & 1);                                       // the previous step's buffer
+        if (s == 0) rebuild(k);
+        if (gs + 1 < total) fill_load(gs + 1);
+        // relu(conv2) of the row this wave will finish after the barrier (row 2s + kh)
+        {
+            const float* ap = act2 + ((clip * kTH + kH3Rows * s + kh) * kTW + 4 * grp) * L::CIN + 16 * nt + ln;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a2v[mt][j] = ap[(16 * mt + j) * L::CIN];
+        }
+        f32x4 acc[2][2];                                            // [row of the step][m-tile]
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][mt][j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = kH3Rows * s + r;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + 1 - dy;                          // mask row of tap dy
+                if (yy >= 0 && yy < kTH) {                          // wave-uniform
+                    const char* rowp = abase + ((k * kTH + yy) % kH3Ring) * L::kGRow;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            const int ks = (dy * 3 + dx) * 2 + kb;
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) {
+                                const half8 a = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp + (16 * mt + 1 - dx) * L::kGRec + kb * 64));
+                                acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[ks], acc[r][mt], 0, 0, 0);
+                                acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl[ks], acc[r][mt], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+        }
+        // park the other row's partial for the partner, keep this wave's own row
+        {
+            float* xw = xch + (((((gs & 1) * 4 + nt) * 2 + kh) * 2) * 4) * 64 + lane;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xw[(mt * 4 + j) * 64] = kh == 0 ? acc[1][mt][j] : acc[0][mt][j];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) keep[mt] = kh == 0 ? acc[0][mt] : acc[1][mt];
+            keep_scale = dscale;
+            keep_clip = clip;
+            keep_y = kH3Rows * s + kh;
+        }
+        if (gs + 1 < total) fill_store(gs + 1);
+        __syncthreads();
+    }
+    finish((total + 1) & 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int train_h_opt_in() {
@@ -911,6 +1130,7 @@ static int train_h_opt_in() {
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WgH::kLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DgH::kLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wg3H::kLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_dgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Dg3H::kLds));
     done[dev] = true;
     return WW_OK;
 }
@@ -943,12 +1163,28 @@ int launch_conv3_wgrad_h(const float* act2, const float* apow2, const uint32_t* 
     return WW_OK;
 }
 
-// dgrad scratch (floats): wp [2*18*64*8], wmax [4], gpmax [n]
-int64_t dgrad_h_scratch_floats(int64_t n) { return 2 * 18 * 64 * 8 + 4 + ((n + 3) & ~int64_t(3)); }
+// dgrad scratch (floats): wp [2*18*64*8 | 4*2*18*64*8], wmax [4], gpmax [n]
+static int64_t wp_floats(int n_conv) { return n_conv == 3 ? 4 * 2 * 18 * 64 * 8 : 2 * 18 * 64 * 8; }
+int64_t dgrad_h_scratch_floats(int64_t n, int n_conv) { return wp_floats(n_conv) + 4 + ((n + 3) & ~int64_t(3)); }
 
-int launch_gp_max(const float* dpooled, float s, int64_t n, float* gp, float* scratch, hipStream_t st) {
-    float* gpmax = scratch + 2 * 18 * 64 * 8 + 4;
-    hipLaunchKernelGGL(gp_max_kernel, dim3(unsigned((n + 3) / 4)), dim3(256), 0, st, dpooled, s, int(n), gp, gpmax);
+int launch_gp_max(const float* dpooled, float s, int64_t n, int n_conv, float* gp, float* scratch, hipStream_t st) {
+    float* gpmax = scratch + wp_floats(n_conv) + 4;
+    if (n_conv == 3) hipLaunchKernelGGL(gp_max128_kernel, dim3(unsigned((n + 3) / 4)), dim3(256), 0, st, dpooled, s, int(n), gp, gpmax);
+    else hipLaunchKernelGGL(gp_max_kernel, dim3(unsigned((n + 3) / 4)), dim3(256), 0, st, dpooled, s, int(n), gp, gpmax);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+int launch_conv3_dgrad_h(const float* act2, const uint32_t* maskbits, const float* gp, const float* w3, float* scratch, int64_t n, float* dz2,
+                         int grid, hipStream_t st) {
+    if (int rc = train_h_opt_in()) return rc;
+    float* wp = scratch;
+    float* wmax = scratch + wp_floats(3);
+    float* gpmax = wmax + 4;
+    WW_HIP(hipMemsetAsync(wmax, 0, 16, st));
+    hipLaunchKernelGGL(pack_dgrad3_h_dev_kernel, dim3(144), dim3(256), 0, st, w3, wp, reinterpret_cast<unsigned int*>(wmax));
+    hipLaunchKernelGGL(conv3_dgrad_h_kernel, dim3(grid), dim3(512), Dg3H::kLds, st, act2, reinterpret_cast<const uint8_t*>(maskbits), gp, gpmax,
+                       wp, wmax, int(n), dz2);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
@@ -957,7 +1193,7 @@ int launch_conv2_dgrad_h(const float* mel, const uint32_t* maskbits, const uint3
                          int64_t n, int width, float* partial, int grid, hipStream_t st) {
     if (int rc = train_h_opt_in()) return rc;
     float* wp = scratch;
-    float* wmax = scratch + 2 * 18 * 64 * 8;
+    float* wmax = scratch + wp_floats(2);
     float* gpmax = wmax + 4;
     WW_HIP(hipMemsetAsync(wmax, 0, 16, st));
     hipLaunchKernelGGL(pack_dgrad_h_dev_kernel, dim3(36), dim3(256), 0, st, w2, wp, reinterpret_cast<unsigned int*>(wmax));
