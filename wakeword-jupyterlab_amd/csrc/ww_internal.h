@@ -152,9 +152,15 @@ int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float
 int launch_conv3_wgrad_h(const float* act2, const float* apow2, const uint32_t* maskbits, const float* gp, int64_t n, float* partial,
                          float* reduced, int grid, hipStream_t st);
 int64_t dgrad_h_scratch_floats(int64_t n, int n_conv);
+float* dgrad_h_scratch2(float* scratch, int64_t n);
+float* dgrad_h_dzs(float* scratch, int64_t n);
+int launch_conv2_wgrad_h_dense(const float* mel, const float* dz2h, const float* dzs, int64_t n, int width, const float* packed, float* partial,
+                               int grid, hipStream_t st);
+int launch_conv2_dgrad_h_dense(const float* mel, const float* dz2h, const float* dzs, const uint32_t* bits1, const float* w2, float* scratch2,
+                               int64_t n, int width, float* partial, int grid, hipStream_t st);
 int launch_gp_max(const float* dpooled, float s, int64_t n, int n_conv, float* gp, float* scratch, hipStream_t st);
-int launch_conv3_dgrad_h(const float* act2, const uint32_t* maskbits, const float* gp, const float* w3, float* scratch, int64_t n, float* dz2,
-                         int grid, hipStream_t st);
+int launch_conv3_dgrad_h(const float* act2, const uint32_t* maskbits, const float* gp, const float* w3, float* scratch, int64_t n, float* dz2h,
+                         float* dzs, int grid, hipStream_t st);
 int launch_conv2_dgrad_h(const float* mel, const uint32_t* maskbits, const uint32_t* bits1, const float* gp, const float* w2, float* scratch,
                          int64_t n, int width, float* partial, int grid, hipStream_t st);
 

@@ -763,14 +763,16 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
             if (int rc = reduce_to(w, grid, kWg3Partial, 128 * 64 * 9, g->conv_weight[2], g->conv_bias[2], 128, st)) return rc;
         }
         if (bits) {
-            if (int rc = launch_conv3_dgrad_h(w.mid2, w.maskbits, w.gp, p->conv_weight[2], w.dgh, n, w.dz2, grid, st)) return rc;
+            if (int rc = launch_conv3_dgrad_h(w.mid2, w.maskbits, w.gp, p->conv_weight[2], w.dgh, n, w.dz2, dgrad_h_dzs(w.dgh, n), grid, st)) return rc;
         } else
             hipLaunchKernelGGL((conv_dgrad_kernel<64, 128, false, false>), dim3(grid), dim3(512), kDg3Lds, st,
                                mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
         WW_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], 64, 32, w.dgrad2_b_op);
-    if (nc == 3)
+    if (nc == 3 && bits) {
+        if (int rc = launch_conv2_wgrad_h_dense(mel, w.dz2, dgrad_h_dzs(w.dgh, n), n, width, w.wpk, w.partial, grid, st)) return rc;
+    } else if (nc == 3)
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 8, true, true>), dim3(grid), dim3(512), kWg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.partial);
     else if (split) {
@@ -780,7 +782,10 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
                            mel, static_cast<const float*>(nullptr), w.mid2, w.gp, N, width, w1, b1, w.partial);
     WW_HIP(hipGetLastError());
     if (int rc = reduce_to(w, grid, kWg2Partial, 64 * 32 * 9, g->conv_weight[1], g->conv_bias[1], 64, st)) return rc;
-    if (nc == 3)
+    if (nc == 3 && bits) {
+        if (int rc = launch_conv2_dgrad_h_dense(mel, w.dz2, dgrad_h_dzs(w.dgh, n), w.bits1, p->conv_weight[1], dgrad_h_scratch2(w.dgh, n), n, width,
+                                                w.partial, grid, st)) return rc;
+    } else if (nc == 3)
         hipLaunchKernelGGL((conv_dgrad_kernel<32, 64, true, true>), dim3(grid), dim3(256), kDg2Lds, st,
                            mel, static_cast<const float*>(nullptr), w.dz2, w.gp, N, width, w1, b1, w.dgrad2_b_op, w.partial);
     else if (split) {

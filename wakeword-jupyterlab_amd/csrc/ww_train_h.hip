@@ -214,9 +214,13 @@ __global__ void relu_mask_bits_kernel(const float* __restrict__ act, int C, uint
 // Output: one partial [64][32][9] + [64] per workgroup (the layout of conv_wgrad_kernel) -> reduce_partials_kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int kHRows = 4, kHSteps = kTH / kHRows, kHGRing = 10;
-struct WgH {
+// DENSE (the 3-conv model's conv2, whose gradient is not rank one): the A operand is dz2 itself, pre-split by conv3_dgrad_h_kernel
+// (f16 records [row][column][64 hi | 64 lo] of dz2 2^-edz, dzs[clip] = 2^edz): 272-byte records, three MFMAs per block
+// (A_hi B_hi + A_hi B_lo + A_lo B_hi), dW += 2^(edz + a - 1) S.
+template <bool DENSE>
+struct WgHT {
     static constexpr int CIN = 32, COUT = 64;
-    static constexpr int kARec = CIN * 4 + 16, kGRec = COUT * 2 + 16;     // 144, 144 bytes
+    static constexpr int kARec = CIN * 4 + 16, kGRec = DENSE ? COUT * 4 + 16 : COUT * 2 + 16;     // 144; 144 | 272 bytes
     static constexpr int kARow = 34 * kARec, kGRow = 32 * kGRec;
     static constexpr int kOffA = kHGRing * kGRow;
     static constexpr int kOffMel = kOffA + 2 * kHRows * kARow;
@@ -224,14 +228,18 @@ struct WgH {
     static constexpr int kLds = kOffLut + 256 * 16;
     static constexpr int kPartial = COUT * CIN * 9 + COUT;
 };
-static_assert(WgH::kLds <= 160 * 1024 && WgH::kOffA % 16 == 0 && WgH::kOffMel % 16 == 0 && WgH::kOffLut % 16 == 0, "LDS map");
+using WgH = WgHT<false>;
+static_assert(WgHT<true>::kLds <= 160 * 1024 && WgH::kOffA % 16 == 0 && WgH::kOffMel % 16 == 0 && WgH::kOffLut % 16 == 0 &&
+              WgHT<true>::kOffA % 16 == 0 && WgHT<true>::kOffMel % 16 == 0, "LDS map");
 
+// maskbits: !DENSE the ReLU bit image [n][80][32][8 bytes];  DENSE the dz2 records (16 x 16 bytes per position).  gp: !DENSE [n][64];  DENSE dzs [n].
+template <bool DENSE>
 __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __restrict__ mel, const uint8_t* __restrict__ maskbits,
                                                                const float* __restrict__ gp, int n, int width,
                                                                const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
                                                                const float* __restrict__ b1, const float* __restrict__ rng,
                                                                float* __restrict__ partial) {
-    using L = WgH;
+    using L = WgHT<DENSE>;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* gring = ldsb;
     char* aring = ldsb + L::kOffA;
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
     u32x4* lut = reinterpret_cast<u32x4*>(ldsb + L::kOffLut);
     __shared__ uint32_t melmax[2];
     __shared__ int clip_ea[2][2];                              // per clip parity: input exponent e, activation exponent a
-    __shared__ float clip_up[2];                               // 2^a / 2: the tile holds 2 relu(conv1) 2^-a
+    __shared__ float clip_up[2], clip_dz[2];                   // 2^a / 2 (x 2^edz): the tile holds 2 relu(conv1) 2^-a;  2^edz
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,7 +281,12 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
         const float mx = __uint_as_float(melmax[k & 1]);
         const int e = clampi(exp_of(mx) - 14, -100, 113);
         const int a = clampi(exp_of(fmaf(mx, rng[0], rng[1])) - 13, -100, 100);
-        if (ptid == 0) { clip_ea[k & 1][0] = e; clip_ea[k & 1][1] = a; clip_up[k & 1] = 0.5f * pow2i(a); }
+        if (ptid == 0) {
+            clip_ea[k & 1][0] = e; clip_ea[k & 1][1] = a;
+            const float dz = DENSE ? gp[int64_t(blockIdx.x) + int64_t(k) * gridDim.x] : 1.0f;      // 2^edz
+            clip_up[k & 1] = 0.5f * pow2i(a) * dz;
+            clip_dz[k & 1] = dz;
+        }
         const int xx = ptid & 31, y0 = ptid >> 5;
         if (xx < width) {
             const float* __restrict__ sp = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kTH * width + y0 * width + xx;
@@ -312,10 +325,17 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
         // mask rows of this step: 0 .. 4 for the clip's first step, else 4s+1 .. 4s+4 (rows beyond 79 do not exist)
         const int g0 = s == 0 ? 0 : 4 * s + 1, g1 = 4 * s + 4 < kTH ? 4 * s + 4 : kTH - 1;
         uint8_t mb[5];
+        u32x4 dzh[DENSE ? 5 : 1], dzl[DENSE ? 5 : 1];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int g = g0 + i;
-            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mcol) * 8 + mcg] : uint8_t(0);
+            if constexpr (DENSE) {
+                const u32x4* rec = reinterpret_cast<const u32x4*>(maskbits) + ((clip * kTH + (g <= g1 ? g : g1)) * kTW + mcol) * 16 + mcg;
+                dzh[i] = rec[0];
+                dzl[i] = rec[8];
+            } else {
+                mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mcol) * 8 + mcg] : uint8_t(0);
+            }
         }
         if (s == 0) {                                            // the clip's scales: bias in the accumulator's scale, descale
             const int e = clip_ea[k & 1][0], a = clip_ea[k & 1][1];
@@ -350,7 +370,13 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
             const int g = g0 + i;
             if (g <= g1) {
                 const int slot = (k * kTH + g) % kHGRing;
-                *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + mcol * L::kGRec + mcg * 16) = lut[mb[i]];
+                char* rec = gring + slot * L::kGRow + mcol * L::kGRec + mcg * 16;
+                if constexpr (DENSE) {
+                    *reinterpret_cast<u32x4*>(rec) = dzh[i];
+                    *reinterpret_cast<u32x4*>(rec + L::COUT * 2) = dzl[i];
+                } else {
+                    *reinterpret_cast<u32x4*>(rec) = lut[mb[i]];
+                }
             }
         }
         // the next clip's planes and exponents, well ahead of its first step (barriers separate the three stages)
@@ -382,22 +408,31 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
         for (int j = 0; j < 4; ++j) { S[t][j] = 0.f; dW[t][j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { cnt[j] = 0.f; dbv[j] = 0.f; }
-    half8 a_prev, a_cur, a_next, ones;
+    struct APair { half8 h, l; };                                // A fragment: the mask (l unused), or dz2's hi and lo halves
+    APair a_prev, a_cur, a_next;
+    half8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { a_prev[j] = 0; a_cur[j] = 0; a_next[j] = 0; ones[j] = static_cast<_Float16>(1.0f); }
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_a = [&](int k, int g) -> half8 {
+    for (int j = 0; j < 8; ++j) {
+        a_prev.h[j] = 0; a_cur.h[j] = 0; a_next.h[j] = 0; a_prev.l[j] = 0; a_cur.l[j] = 0; a_next.l[j] = 0;
+        ones[j] = static_cast<_Float16>(1.0f);
+    }
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    auto load_a = [&](int k, int g) -> APair {
         const char* r = abase + ((k * kTH + g) % kHGRing) * L::kGRow;
-        return cat8(lds_tr16(r), lds_tr16(r + L::kGRec));
+        APair f;
+        f.h = cat8(lds_tr16(r), lds_tr16(r + L::kGRec));
+        if constexpr (DENSE) f.l = cat8(lds_tr16(r + L::COUT * 2), lds_tr16(r + L::kGRec + L::COUT * 2));
+        else f.l = f.h;
+        return f;
     };
     auto consume = [&](int gs) {
         const int k = gs / kHSteps, s = gs - k * kHSteps;
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
         if (s == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a_prev[j] = 0;
+            for (int j = 0; j < 8; ++j) { a_prev.h[j] = 0; a_prev.l[j] = 0; }
             a_cur = load_a(k, 0);
-            g4 = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 16 * ct + 4 * grp);
+            if constexpr (!DENSE) g4 = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 16 * ct + 4 * grp);
         }
 #pragma unroll
         for (int i = 0; i < kHRows; ++i) {
@@ -405,7 +440,7 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
             if (r + 1 < kTH) a_next = load_a(k, r + 1);
             else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a_next[j] = 0;
+                for (int j = 0; j < 8; ++j) { a_next.h[j] = 0; a_next.l[j] = 0; }
             }
             const char* br = bbase + ((gs & 1) * kHRows + i) * L::kARow;
             half8 bh[3], bl[3];
@@ -417,14 +452,16 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const half8 ay = dy == 0 ? a_next : (dy == 1 ? a_cur : a_prev);       // mask row r - dy + 1
+                const APair ay = dy == 0 ? a_next : (dy == 1 ? a_cur : a_prev);       // gradient row r - dy + 1
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    S[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay, bh[dx], S[dy * 3 + dx], 0, 0, 0);
-                    S[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay, bl[dx], S[dy * 3 + dx], 0, 0, 0);
+                    S[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay.h, bh[dx], S[dy * 3 + dx], 0, 0, 0);
+                    S[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay.h, bl[dx], S[dy * 3 + dx], 0, 0, 0);
+                    if constexpr (DENSE) S[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ay.l, bh[dx], S[dy * 3 + dx], 0, 0, 0);
                 }
             }
-            cnt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, ones, cnt, 0, 0, 0);  // positions with mask 1, per channel
+            cnt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur.h, ones, cnt, 0, 0, 0);  // sum over positions of the gradient row, per channel
+            if constexpr (DENSE) cnt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur.l, ones, cnt, 0, 0, 0);
             a_prev = a_cur;
             a_cur = a_next;
         }
@@ -437,7 +474,7 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { dW[t][j] = fmaf(gj[j], S[t][j] * up, dW[t][j]); S[t][j] = 0.f; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { dbv[j] = fmaf(gj[j], cnt[j], dbv[j]); cnt[j] = 0.f; }
+            for (int j = 0; j < 4; ++j) { dbv[j] = fmaf(gj[j] * clip_dz[k & 1], cnt[j], dbv[j]); cnt[j] = 0.f; }
         }
     };
 
@@ -688,9 +725,12 @@ __global__ void reduce_wgrad3_h_kernel(const float* __restrict__ partial, int gr
 // Output: one partial [32][9] + [32] (float; summed over the workgroup in double) per workgroup -> reduce_partials_kernel.
 // ------------------------------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
-struct DgH {
+// DENSE (the 3-conv model's conv2): A = dz2 pre-split by conv3_dgrad_h_kernel (f16 records [64 hi | 64 lo], 288 bytes in LDS), B = W2 2^-ew
+// as hi + lo built ONCE per launch, three MFMAs per block (A_hi B_hi + A_hi B_lo + A_lo B_hi), da1 = 2^(ew + edz) x the accumulator.
+template <bool DENSE>
+struct DgHT {
     static constexpr int CIN = 32, COUT = 64;
-    static constexpr int kGRec = 160, kGRow = 34 * kGRec;                   // columns -1..32, conflict-free 16-byte row reads
+    static constexpr int kGRec = DENSE ? 288 : 160, kGRow = 34 * kGRec;     // columns -1..32, conflict-free 16-byte row reads
     static constexpr int kMelRS = 36, kMelFloats = (kTH + 2) * kMelRS;      // fp32 log-mel tile with a zero halo
     static constexpr int kOffMel = kHGRing * kGRow;
     static constexpr int kOffS1 = kOffMel + 2 * kMelFloats * 4;             // conv1 sign words: 2 steps x 4 rows x 32 columns
@@ -698,7 +738,9 @@ struct DgH {
     static constexpr int kLds = kOffLut + 256 * 16;
     static constexpr int kPartial = CIN * 9 + CIN;
 };
-static_assert(DgH::kLds <= 160 * 1024 && DgH::kOffMel % 16 == 0 && DgH::kOffS1 % 16 == 0 && DgH::kOffLut % 16 == 0, "LDS map");
+using DgH = DgHT<false>;
+static_assert(DgHT<true>::kLds <= 160 * 1024 && DgH::kOffMel % 16 == 0 && DgH::kOffS1 % 16 == 0 && DgH::kOffLut % 16 == 0 &&
+              DgHT<true>::kOffMel % 16 == 0 && DgHT<true>::kOffS1 % 16 == 0, "LDS map");
 
 // W2 [64][32][3][3] -> the lane order of the B operand: wp[((nt*18 + ks)*64 + lane)*8 + j] = W2[32 kb + 8 g + j][16 nt + n][dy][dx],
 // ks = (dy*3 + dx)*2 + kb, lane = n + 16 g; wmax = max |W2| (float bits, zeroed by the caller)
@@ -725,12 +767,14 @@ __global__ void gp_max_kernel(const float* __restrict__ dpooled, float s, int n,
     if (lane == 0) gpmax[b] = m;
 }
 
+// maskbits: !DENSE the ReLU bit image of conv2;  DENSE the dz2 records.  gpmax: !DENSE max |gp| per clip;  DENSE dzs [n] (2^edz).  gp unused if DENSE.
+template <bool DENSE>
 __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __restrict__ mel, const uint8_t* __restrict__ maskbits,
                                                                const uint32_t* __restrict__ bits1, const float* __restrict__ gp,
                                                                const float* __restrict__ gpmax, const float* __restrict__ wp,
                                                                const float* __restrict__ w2max, int n, int width,
                                                                float* __restrict__ partial) {
-    using L = DgH;
+    using L = DgHT<DENSE>;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* gring = ldsb;
     float* meltile = reinterpret_cast<float*>(ldsb + L::kOffMel);
@@ -762,28 +806,49 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
     };
     // the rows a step needs beyond what is already in LDS: mask rows 0..4 (first step of a clip) or 4s+1..4s+4, conv1 sign rows 4s..4s+3
     const int mcg = tid & 7, mpos = tid >> 3;                       // mask role: byte (8 channels), position 0..63 (+64 per pass)
+    const int dchunk = tid & 15, dpos = tid >> 4;                   // DENSE: 16-byte chunk of the 256-byte record, position 0..31 (+32 per pass)
     uint8_t mb[3];
+    u32x4 dzr[DENSE ? 5 : 1];
     uint32_t sw_next = 0u;
     auto fill_load = [&](int gs) {                                 // issue the global loads early ...
         const int k = gs / kHSteps, s = gs - k * kHSteps;
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
         const int g0 = s == 0 ? 0 : 4 * s + 1, g1 = 4 * s + 4 < kTH ? 4 * s + 4 : kTH - 1;
+        if constexpr (DENSE) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
-            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + (pos & 31)) * 8 + mcg] : uint8_t(0);
+            for (int i = 0; i < 5; ++i) {
+                const int g = g0 + i <= g1 ? g0 + i : g1;
+                dzr[i] = reinterpret_cast<const u32x4*>(maskbits)[((clip * kTH + g) * kTW + dpos) * 16 + dchunk];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
+                mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + (pos & 31)) * 8 + mcg] : uint8_t(0);
+            }
         }
         if (tid < kHRows * kTW) sw_next = bits1[(clip * kTH + kHRows * s) * kTW + tid];
     };
     auto fill_store = [&](int gs) {                                // ... and expand them into LDS behind the step's matrix work
         const int k = gs / kHSteps, s = gs - k * kHSteps;
         const int g0 = s == 0 ? 0 : 4 * s + 1, g1 = 4 * s + 4 < kTH ? 4 * s + 4 : kTH - 1;
+        if constexpr (DENSE) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
-            if (g <= g1) {
-                const int slot = (k * kTH + g) % kHGRing;
-                *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + ((pos & 31) + 1) * L::kGRec + mcg * 16) = lut[mb[i]];
+            for (int i = 0; i < 5; ++i) {
+                const int g = g0 + i;
+                if (g <= g1) {
+                    const int slot = (k * kTH + g) % kHGRing;
+                    *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + (dpos + 1) * L::kGRec + dchunk * 16) = dzr[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
+                if (g <= g1) {
+                    const int slot = (k * kTH + g) % kHGRing;
+                    *reinterpret_cast<u32x4*>(gring + slot * L::kGRow + ((pos & 31) + 1) * L::kGRec + mcg * 16) = lut[mb[i]];
+                }
             }
         }
         if (tid < kHRows * kTW) s1rows[(gs & 1) * kHRows * kTW + tid] = sw_next;
@@ -796,15 +861,18 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
     float dscale = 0.f;
     auto rebuild = [&](int k) {
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-        const int eg = clampi(exp_of(gpmax[clip] * w2max[0]) - 12, -100, 100);
+        // !DENSE: G = gp[b] W2 2^-eg, per clip.  DENSE: W2 2^-ew once (k == 0), the clip only changes the descale 2^(ew + edz)
+        const int eg = clampi(exp_of((DENSE ? 1.0f : gpmax[clip]) * w2max[0]) - 12, -100, 100);
         const float down = pow2i(-eg);
-        dscale = pow2i(eg);
+        dscale = DENSE ? pow2i(eg) * gpmax[clip] : pow2i(eg);
+        if (DENSE && k > 0) return;
         float gv[16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int q4 = 0; q4 < 2; ++q4) {
-                const float4 v = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 32 * kb + 8 * grp + 4 * q4);
+                float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+                if constexpr (!DENSE) v = *reinterpret_cast<const float4*>(gp + clip * L::COUT + 32 * kb + 8 * grp + 4 * q4);
                 gv[8 * kb + 4 * q4] = v.x * down; gv[8 * kb + 4 * q4 + 1] = v.y * down; gv[8 * kb + 4 * q4 + 2] = v.z * down; gv[8 * kb + 4 * q4 + 3] = v.w * down;
             }
         const float4* w4 = reinterpret_cast<const float4*>(wp) + (int64_t(nt) * 18 * 64 + lane) * 2;
@@ -856,6 +924,10 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
                             const half8 a = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp + (16 * mt + 1 - dx) * L::kGRec + kb * 64));
                             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[ks], acc[mt], 0, 0, 0);
                             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl[ks], acc[mt], 0, 0, 0);
+                            if constexpr (DENSE) {
+                                const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp + (16 * mt + 1 - dx) * L::kGRec + 128 + kb * 64));
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[mt], 0, 0, 0);
+                            }
                         }
                     }
             }
@@ -905,8 +977,10 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
 // K = 128 co x 9 taps = 36 k-steps per N-tile of 16 ci: 288 B-operand VGPRs -- split over TWO waves (kh = co half, 144 VGPRs each);
 // 8 waves = (4 N-tiles) x (2 K halves), every wave runs both rows of a two-row step.  The halves meet through LDS: wave kh finishes
 // row 2s + kh -- it parks the partial tile of the OTHER row in the exchange buffer, and after the step's barrier adds its partner's partial
-// of its own row, applies relu(conv2)'s sign (float32 channels last, loaded a step ahead) and stores dz2 as [row][channel][column]
-// (what the exact-fp32 conv2 kernels below take).  Mask ring: 6 rows of 288-byte records (128 channels; conflict-free 16-byte row reads).
+// of its own row, applies relu(conv2)'s sign (float32 channels last, loaded a step ahead) and stores dz2 ALREADY SPLIT for the conv2
+// kernels below: f16 records [row][column][64 hi | 64 lo] of dz2 2^-edz with one exponent per clip, edz = eg + 10 (|dz2| <= 1152 max|G|,
+// so the records stay below 2^14 whatever the clip; typical values sit 2^6 lower, where hi and lo are still normal f16), dzs[clip] = 2^edz.
+// Mask ring: 6 rows of 288-byte records (128 channels; conflict-free 16-byte row reads).
 // ------------------------------------------------------------------------------------------------
 constexpr int kH3Rows = 2, kH3Steps = kTH / kH3Rows, kH3Ring = 6;
 struct Dg3H {
@@ -947,7 +1021,8 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
                                                                const uint8_t* __restrict__ maskbits /*[n][80][32][16 bytes]*/,
                                                                const float* __restrict__ gp, const float* __restrict__ gpmax,
                                                                const float* __restrict__ wp, const float* __restrict__ w3max, int n,
-                                                               float* __restrict__ dz2 /*[n][80][64][32]*/) {
+                                                               _Float16* __restrict__ dz2h /*[n][80][32][64 hi | 64 lo]*/,
+                                                               float* __restrict__ dzs /*[n]: 2^edz*/) {
     using L = Dg3H;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* gring = ldsb;
@@ -996,12 +1071,11 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
     };
 
     half8 bh[18], bl[18];
-    float dscale = 0.f;
     auto rebuild = [&](int k) {
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
         const int eg = clampi(exp_of(gpmax[clip] * w3max[0]) - 12, -100, 100);
         const float down = pow2i(-eg);
-        dscale = pow2i(eg);
+        if (tid == 0) dzs[clip] = pow2i(eg + 10);
         float gv[16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -1033,7 +1107,6 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
     const char* abase = gring + (ln + 1) * L::kGRec + kh * 128 + grp * 16;   // A: row = column ln of the m-tile, this wave's 64 co, 8 per lane group
     f32x4 keep[2];                                                  // this wave's own partial of the row it finishes (row 2s + kh), per m-tile
     float a2v[2][4];                                                // relu(conv2) at that row: columns 16 mt + 4 grp + j, channel 16 nt + ln
-    float keep_scale = 0.f;
     int64_t keep_clip = 0;
     int keep_y = -1;
 #pragma unroll
@@ -1044,16 +1117,16 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
     auto finish = [&](int buf) {
         if (keep_y < 0) return;
         const float* xp = xch + ((((buf * 4 + nt) * 2 + (kh ^ 1)) * 2) * 4) * 64 + lane;
-        float* out = dz2 + ((keep_clip * kTH + keep_y) * L::CIN + 16 * nt + ln) * kTW + 4 * grp;
+        _Float16* out = dz2h + ((keep_clip * kTH + keep_y) * kTW + 4 * grp) * 128 + 16 * nt + ln;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            float4 v;
-            v.x = a2v[mt][0] > 0.f ? (keep[mt][0] + xp[(mt * 4 + 0) * 64]) * keep_scale : 0.f;
-            v.y = a2v[mt][1] > 0.f ? (keep[mt][1] + xp[(mt * 4 + 1) * 64]) * keep_scale : 0.f;
-            v.z = a2v[mt][2] > 0.f ? (keep[mt][2] + xp[(mt * 4 + 2) * 64]) * keep_scale : 0.f;
-            v.w = a2v[mt][3] > 0.f ? (keep[mt][3] + xp[(mt * 4 + 3) * 64]) * keep_scale : 0.f;
-            *reinterpret_cast<float4*>(out + 16 * mt) = v;
-        }
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = a2v[mt][j] > 0.f ? (keep[mt][j] + xp[(mt * 4 + j) * 64]) * 0x1p-10f : 0.f;   // da 2^-eg 2^-10 = dz2 2^-edz
+                const _Float16 hi = static_cast<_Float16>(v);
+                out[(16 * mt + j) * 128] = hi;
+                out[(16 * mt + j) * 128 + 64] = static_cast<_Float16>(v - static_cast<float>(hi));
+            }
     };
     for (int gs = 0; gs < total; ++gs) {
         const int k = gs / kH3Steps, s = gs - k * kH3Steps;
@@ -1108,7 +1181,6 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
                 for (int j = 0; j < 4; ++j) xw[(mt * 4 + j) * 64] = kh == 0 ? acc[1][mt][j] : acc[0][mt][j];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) keep[mt] = kh == 0 ? acc[0][mt] : acc[1][mt];
-            keep_scale = dscale;
             keep_clip = clip;
             keep_y = kH3Rows * s + kh;
         }
@@ -1127,8 +1199,10 @@ static int train_h_opt_in() {
     WW_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
     if (done[dev]) return WW_OK;
-    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WgH::kLds));
-    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DgH::kLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WgH::kLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_wgrad_h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WgHT<true>::kLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DgH::kLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DgHT<true>::kLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wg3H::kLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_dgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Dg3H::kLds));
     done[dev] = true;
@@ -1145,9 +1219,21 @@ int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float
                          float* partial, int grid, hipStream_t st) {
     if (int rc = train_h_opt_in()) return rc;
     const PackedLayout P = packed_layout(2);
-    hipLaunchKernelGGL(conv2_wgrad_h_kernel, dim3(grid), dim3(768), WgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), gp, int(n),
+    hipLaunchKernelGGL(conv2_wgrad_h_kernel<false>, dim3(grid), dim3(768), WgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), gp, int(n),
                        width, reinterpret_cast<const u32x4*>(packed + P.conv1_h), packed + P.conv1_hs, packed + P.conv1_b, packed + P.range,
                        partial);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// conv2 weight gradient of the 3-conv model from the pre-split dense gradient dz2h (conv3_dgrad_h_kernel)
+int launch_conv2_wgrad_h_dense(const float* mel, const float* dz2h, const float* dzs, int64_t n, int width, const float* packed, float* partial,
+                               int grid, hipStream_t st) {
+    if (int rc = train_h_opt_in()) return rc;
+    const PackedLayout P = packed_layout(3);
+    hipLaunchKernelGGL(conv2_wgrad_h_kernel<true>, dim3(grid), dim3(768), WgHT<true>::kLds, st, mel, reinterpret_cast<const uint8_t*>(dz2h), dzs,
+                       int(n), width, reinterpret_cast<const u32x4*>(packed + P.conv1_h), packed + P.conv1_hs, packed + P.conv1_b,
+                       packed + P.range, partial);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
@@ -1165,7 +1251,10 @@ int launch_conv3_wgrad_h(const float* act2, const float* apow2, const uint32_t* 
 
 // dgrad scratch (floats): wp [2*18*64*8 | 4*2*18*64*8], wmax [4], gpmax [n]
 static int64_t wp_floats(int n_conv) { return n_conv == 3 ? 4 * 2 * 18 * 64 * 8 : 2 * 18 * 64 * 8; }
-int64_t dgrad_h_scratch_floats(int64_t n, int n_conv) { return wp_floats(n_conv) + 4 + ((n + 3) & ~int64_t(3)); }
+int64_t dgrad_h_scratch_floats(int64_t n, int n_conv) { return wp_floats(n_conv) + 4 + ((n + 3) & ~int64_t(3)) + (n_conv == 3 ? wp_floats(2) + 4 + ((n + 3) & ~int64_t(3)) : 0); }
+// 3-conv layout of the scratch: [conv3: wp, wmax, gpmax[n]] [conv2: wp, wmax] [dzs[n]]
+float* dgrad_h_scratch2(float* scratch, int64_t n) { return scratch + wp_floats(3) + 4 + ((n + 3) & ~int64_t(3)); }
+float* dgrad_h_dzs(float* scratch, int64_t n) { return dgrad_h_scratch2(scratch, n) + wp_floats(2) + 4; }
 
 int launch_gp_max(const float* dpooled, float s, int64_t n, int n_conv, float* gp, float* scratch, hipStream_t st) {
     float* gpmax = scratch + wp_floats(n_conv) + 4;
@@ -1175,8 +1264,8 @@ int launch_gp_max(const float* dpooled, float s, int64_t n, int n_conv, float* g
     return WW_OK;
 }
 
-int launch_conv3_dgrad_h(const float* act2, const uint32_t* maskbits, const float* gp, const float* w3, float* scratch, int64_t n, float* dz2,
-                         int grid, hipStream_t st) {
+int launch_conv3_dgrad_h(const float* act2, const uint32_t* maskbits, const float* gp, const float* w3, float* scratch, int64_t n, float* dz2h,
+                         float* dzs, int grid, hipStream_t st) {
     if (int rc = train_h_opt_in()) return rc;
     float* wp = scratch;
     float* wmax = scratch + wp_floats(3);
@@ -1184,7 +1273,7 @@ int launch_conv3_dgrad_h(const float* act2, const uint32_t* maskbits, const floa
     WW_HIP(hipMemsetAsync(wmax, 0, 16, st));
     hipLaunchKernelGGL(pack_dgrad3_h_dev_kernel, dim3(144), dim3(256), 0, st, w3, wp, reinterpret_cast<unsigned int*>(wmax));
     hipLaunchKernelGGL(conv3_dgrad_h_kernel, dim3(grid), dim3(512), Dg3H::kLds, st, act2, reinterpret_cast<const uint8_t*>(maskbits), gp, gpmax,
-                       wp, wmax, int(n), dz2);
+                       wp, wmax, int(n), reinterpret_cast<_Float16*>(dz2h), dzs);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
@@ -1197,8 +1286,22 @@ int launch_conv2_dgrad_h(const float* mel, const uint32_t* maskbits, const uint3
     float* gpmax = wmax + 4;
     WW_HIP(hipMemsetAsync(wmax, 0, 16, st));
     hipLaunchKernelGGL(pack_dgrad_h_dev_kernel, dim3(36), dim3(256), 0, st, w2, wp, reinterpret_cast<unsigned int*>(wmax));
-    hipLaunchKernelGGL(conv2_dgrad_h_kernel, dim3(grid), dim3(512), DgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), bits1, gp,
+    hipLaunchKernelGGL(conv2_dgrad_h_kernel<false>, dim3(grid), dim3(512), DgH::kLds, st, mel, reinterpret_cast<const uint8_t*>(maskbits), bits1, gp,
                        gpmax, wp, wmax, int(n), width, partial);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// conv2 data gradient + conv1 weight gradient of the 3-conv model from the pre-split dense gradient dz2h; scratch2: wp [2*18*64*8] + wmax [4]
+int launch_conv2_dgrad_h_dense(const float* mel, const float* dz2h, const float* dzs, const uint32_t* bits1, const float* w2, float* scratch2,
+                               int64_t n, int width, float* partial, int grid, hipStream_t st) {
+    if (int rc = train_h_opt_in()) return rc;
+    float* wp = scratch2;
+    float* wmax = scratch2 + wp_floats(2);
+    WW_HIP(hipMemsetAsync(wmax, 0, 16, st));
+    hipLaunchKernelGGL(pack_dgrad_h_dev_kernel, dim3(36), dim3(256), 0, st, w2, wp, reinterpret_cast<unsigned int*>(wmax));
+    hipLaunchKernelGGL(conv2_dgrad_h_kernel<true>, dim3(grid), dim3(512), DgHT<true>::kLds, st, mel, reinterpret_cast<const uint8_t*>(dz2h), bits1,
+                       static_cast<const float*>(nullptr), dzs, wp, wmax, int(n), width, partial);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
