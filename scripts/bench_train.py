@@ -55,9 +55,7 @@ def measure(batch=4096, steps=5, device=0, cpu_sample=64, arch="simple", math=No
     return {"workload": f"{'SimpleWakewordModel' if arch == 'simple' else '3-conv WakewordModel'} training step (train-mode forward with dropout + CrossEntropyLoss + backward + Adam), "
                         f"batch {batch}, log-mel inputs resident in HBM; " +
                         ("conv stack in split precision on the f16 matrix cores, conv1 weight gradient on the f64 matrix cores, head exact fp32 "
-                         "(csrc/ww_train_h.hip, ww_train.hip)" if math == "f16x3" and arch == "simple" else
-                         "forward in split precision on the f16 matrix cores (the inference kernels + ReLU bit images), backward exact fp32 "
-                         "(csrc/ww_train.hip)" if math == "f16x3" else "exact fp32 kernels (csrc/ww_train.hip)"),
+                         "(csrc/ww_train_h.hip, ww_train.hip)" if math == "f16x3" else "exact fp32 kernels (csrc/ww_train.hip)"),
             "train_math": math,
             "ms_per_step": dt * 1e3, "clips_per_s": batch / dt, "final_loss": float(loss.item()),
             "cpu_torch_clips_per_s": cpu_sample / dt_cpu, "cpu_threads": int(torch.get_num_threads()), "cpu_sample": cpu_sample}

@@ -140,7 +140,6 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
                    const ww_train_grads* g, hipStream_t st);
 
 int train_math_mode();   // 0 exact fp32, 1 split-precision conv backward where a kernel exists (ww_train_h.hip)
-int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st);
 int launch_pack_conv_h_dev(const ww_train_params* p, float* img, hipStream_t st);
 int launch_cnn3w_pool_bits(const float* mel, int64_t n, int width, const float* packed, float* mid2, float* apow2, float* pooled,
                            uint32_t* bits3, uint32_t* bits1, hipStream_t stream);

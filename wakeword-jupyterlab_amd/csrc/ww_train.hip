@@ -107,8 +107,7 @@ struct WgradCfg {
     static_assert(BAND % kSplits == 0 && kLdsFloats * 4 <= 160 * 1024, "band does not fit");
 };
 
-// BITS (split-precision forward): the mask arrives as bits [b][row][col][COUT bits] and iact as [b][row][col][CIN] (channels last).
-template <int CIN, int COUT, int BAND, bool DENSE, bool FROM_MEL, bool BITS = false>
+template <int CIN, int COUT, int BAND, bool DENSE, bool FROM_MEL>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const float* __restrict__ mel, const float* __restrict__ iact,
                                                             const float* __restrict__ oact_or_dz, const float* __restrict__ gp /*[n][COUT]*/,
                                                             int n, int width, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -162,15 +161,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
                 for (int p = 0; p < kGmPasses; ++p) {
                     const int co = lrow8 + 64 * p;
-                    float4 v;
-                    if constexpr (BITS) {
-                        const uint8_t* mb = reinterpret_cast<const uint8_t*>(oact_or_dz) + ((int64_t(clip) * kTH + y0 + r) * kTW + lcol) * (COUT / 8) + (co >> 3);
-                        const int sh = co & 7;
-                        v = make_float4(float((mb[0] >> sh) & 1), float((mb[COUT / 8] >> sh) & 1), float((mb[2 * (COUT / 8)] >> sh) & 1),
-                                        float((mb[3 * (COUT / 8)] >> sh) & 1));
-                    } else {
-                        v = *reinterpret_cast<const float4*>(oact_or_dz + ((int64_t(clip) * kTH + y0 + r) * COUT + co) * kTW + lcol);
-                    }
+                    const float4 v = *reinterpret_cast<const float4*>(oact_or_dz + ((int64_t(clip) * kTH + y0 + r) * COUT + co) * kTW + lcol);
                     float* d = gm + (r * COUT + co) * 33 + lcol;
                     float g0, g1, g2, g3;
                     if constexpr (DENSE) { g0 = v.x; g1 = v.y; g2 = v.z; g3 = v.w; }
@@ -200,22 +191,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const float* __restr
 #pragma unroll 1
                 for (int q = 0; q < BAND + 2; ++q) {
                     const int y = y0 - 1 + q;
-                    if constexpr (BITS) {      // channels last: thread = (column, 4 channels), 16 lanes cover one position's 256 bytes
-                        static_assert(CIN == 64, "512 threads = 32 columns x 16 groups of 4 channels");
-                        const int col = tid >> 4, c4 = (tid & 15) * 4;
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (y >= 0 && y < kTH) v = *reinterpret_cast<const float4*>(iact + ((int64_t(clip) * kTH + y) * kTW + col) * CIN + c4);
-                        float* d = act + c4 * Cfg::kActCi + q * kTRS + col + 1;
-                        d[0] = v.x; d[Cfg::kActCi] = v.y; d[2 * Cfg::kActCi] = v.z; d[3 * Cfg::kActCi] = v.w;
-                    } else {
 #pragma unroll
-                        for (int p = 0; p < CIN / 64; ++p) {
-                            const int ci = lrow8 + 64 * p;
-                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (y >= 0 && y < kTH) v = *reinterpret_cast<const float4*>(iact + ((int64_t(clip) * kTH + y) * CIN + ci) * kTW + lcol);
-                            float* d = act + ci * Cfg::kActCi + q * kTRS + lcol + 1;
-                            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                        }
+                    for (int p = 0; p < CIN / 64; ++p) {
+                        const int ci = lrow8 + 64 * p;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (y >= 0 && y < kTH) v = *reinterpret_cast<const float4*>(iact + ((int64_t(clip) * kTH + y) * CIN + ci) * kTW + lcol);
+                        float* d = act + ci * Cfg::kActCi + q * kTRS + lcol + 1;
+                        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                     }
                 }
             }
@@ -290,7 +272,7 @@ struct DgradCfg {
 };
 constexpr int kDgPartial = 32 * 9 + 32;
 
-template <int CIN, int COUT, bool DENSE, bool TO_CONV1, bool BITS = false>
+template <int CIN, int COUT, bool DENSE, bool TO_CONV1>
 __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dgrad_kernel(
     const float* __restrict__ mel, const float* __restrict__ iact, const float* __restrict__ oact_or_dz, const float* __restrict__ gp, int n,
     int width, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wB, float* __restrict__ out) {
@@ -334,17 +316,9 @@ __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dg
                 const int y = y0 - 1 + q;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
                 if (y >= 0 && y < kTH) {
-                    if constexpr (BITS) {      // the mask as bits [b][row][col][COUT bits] (split-precision forward): 1.0 where set
-                        const uint8_t* mb = reinterpret_cast<const uint8_t*>(oact_or_dz) + ((int64_t(clip) * kTH + y) * kTW + lcol) * (COUT / 8) + (lco >> 3);
-                        const int sh = lco & 7;
-                        a.x = float((mb[0] >> sh) & 1); a.y = float((mb[COUT / 8] >> sh) & 1); a.z = float((mb[2 * (COUT / 8)] >> sh) & 1);
-                        a.w = float((mb[3 * (COUT / 8)] >> sh) & 1); b.x = float((mb[4 * (COUT / 8)] >> sh) & 1); b.y = float((mb[5 * (COUT / 8)] >> sh) & 1);
-                        b.z = float((mb[6 * (COUT / 8)] >> sh) & 1); b.w = float((mb[7 * (COUT / 8)] >> sh) & 1);
-                    } else {
-                        const float* src = oact_or_dz + ((int64_t(clip) * kTH + y) * COUT + lco) * kTW + lcol;
-                        a = *reinterpret_cast<const float4*>(src);
-                        b = *reinterpret_cast<const float4*>(src + 4);
-                    }
+                    const float* src = oact_or_dz + ((int64_t(clip) * kTH + y) * COUT + lco) * kTW + lcol;
+                    a = *reinterpret_cast<const float4*>(src);
+                    b = *reinterpret_cast<const float4*>(src + 4);
                 }
                 float* d = gmt + (lco * R + q) * kTRS + lcol + 1;
                 if constexpr (DENSE) {
@@ -419,13 +393,7 @@ __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dg
                         const int64_t at = ((int64_t(clip) * kTH + y) * CIN + 32 * nt + ln) * kTW + 4 * h;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
-                            float4 ia;
-                            if constexpr (BITS) {  // relu(conv2) channels last [b][row][col][CIN]: columns 4h + 8gq .. +3 of channel 32 nt + ln
-                                const float* ip = iact + ((int64_t(clip) * kTH + y) * kTW + 4 * h + 8 * gq) * CIN + 32 * nt + ln;
-                                ia = make_float4(ip[0], ip[CIN], ip[2 * CIN], ip[3 * CIN]);
-                            } else {
-                                ia = *reinterpret_cast<const float4*>(iact + at + 8 * gq);
-                            }
+                            const float4 ia = *reinterpret_cast<const float4*>(iact + at + 8 * gq);
                             float4 dz;
                             dz.x = ia.x > 0.f ? acc[r][4 * gq + 0] : 0.f;
                             dz.y = ia.y > 0.f ? acc[r][4 * gq + 1] : 0.f;
@@ -650,7 +618,6 @@ static int train_opt_in() {
     WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<32, 64, 8, true, true>), WgradCfg<32, 64, 8>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_wgrad_kernel<64, 128, 4, false, false>), WgradCfg<64, 128, 4>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, false, true>), DgradCfg<32, 64>::kLdsFloats));
-    WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, false, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<32, 64, true, true>), DgradCfg<32, 64>::kLdsFloats));
     WW_HIP(opt(reinterpret_cast<const void*>(conv_dgrad_kernel<64, 128, false, false>), DgradCfg<64, 128>::kLdsFloats));
     done[dev] = true;

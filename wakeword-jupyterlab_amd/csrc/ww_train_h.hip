@@ -171,30 +171,6 @@ int launch_pack_conv_h_dev(const ww_train_params* p, float* img, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------
-// relu(conv) [b][row][C][32 columns] floats (cnn2_kernel<false> / cnn3_kernel<STORE>) -> mask bits [b][row][32 columns][C/32 words].
-// One workgroup of C threads per (clip, row): thread = channel reads its 32 columns, one ballot per column.
-// ------------------------------------------------------------------------------------------------
-__global__ void relu_mask_bits_kernel(const float* __restrict__ act, int C, uint32_t* __restrict__ bits) {
-    const int64_t row = blockIdx.x;                               // clip * 80 + image row
-    const int ch = threadIdx.x, lane = ch & 63, wv = ch >> 6;
-    const float4* src = reinterpret_cast<const float4*>(act + (row * C + ch) * kTW);
-    float v[32];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const float4 q = src[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
-    unsigned long long mine = 0ull;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(v[c] > 0.f);
-        if (lane == c) mine = m;
-    }
-    if (lane < 32) {
-        uint32_t* o = bits + (row * kTW + lane) * (C / 32) + 2 * wv;
-        o[0] = uint32_t(mine);
-        o[1] = uint32_t(mine >> 32);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Weight gradient of conv2 (32 -> 64) with relu(conv1) recomputed from the log-mel tile.
 //   D[m = co][n = ci] += A[m][k] B[k][n] on v_mfma_f32_16x16x32_f16, k = the 32 columns of one image row:
 //   A = mask row y (exact), B = a1 row y + dy - 1 shifted by dx - 1 (hi, lo): S[dy][dx] += A_y (B_hi + B_lo).
@@ -1206,12 +1182,6 @@ static int train_h_opt_in() {
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wg3H::kLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_dgrad_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Dg3H::kLds));
     done[dev] = true;
-    return WW_OK;
-}
-
-int launch_relu_mask_bits(const float* act, int64_t n, int C, uint32_t* bits, hipStream_t st) {
-    hipLaunchKernelGGL(relu_mask_bits_kernel, dim3(unsigned(n * kTH)), dim3(C), 0, st, act, C, bits);
-    WW_HIP(hipGetLastError());
     return WW_OK;
 }
 
