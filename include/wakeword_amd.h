@@ -279,9 +279,10 @@ WW_API int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, 
 WW_API int ww_train_packed_image(const void* workspace_dev, int64_t n, int32_t n_conv, float* img_dev, ww_stream_t stream);
 /* Arithmetic of the training step's convolution kernels, process-wide (the head is always exact fp32):
  *   WW_TRAIN_MATH_F32    exact fp32 matrix instructions throughout (v_mfma_f32_32x32x2_f32)
- *   WW_TRAIN_MATH_F16X3  (default) split precision on the f16 matrix instructions wherever a kernel exists (SimpleWakewordModel's conv2
- *                        forward = the inference kernel with the ReLU mask as a second output, conv2 backward: one operand is the
- *                        0/1 mask, exact in f16; the other is carried as two f16 halves); the remaining kernels run as under F32.
+ *   WW_TRAIN_MATH_F16X3  (default) the conv stack in split precision on the f16 matrix instructions, for both models: forward = the
+ *                        inference kernels with the ReLU masks as extra outputs (bit images); backward of the last conv: one operand
+ *                        is the 0/1 mask, exact in f16, the other is carried as two f16 halves; below it both operands as two halves;
+ *                        conv1's weight gradient in double on the f64 matrix instructions.  The head runs as under F32.
  *                        Gradients agree with F32 to the 2^-22 of the split.  A step's forward and backward must run under the same mode. */
 #define WW_TRAIN_MATH_F32 0
 #define WW_TRAIN_MATH_F16X3 1
