@@ -1,4 +1,5 @@
-// Training step of SimpleWakewordModel: train-mode forward and the backward pass.
+// Training step of both models: train-mode forward and the backward pass -- orchestration, the head's
+// backward, and the EXACT-FP32 conv kernels (ww_set_train_math(WW_TRAIN_MATH_F32)); the default split-precision conv kernels are in ww_train_h.hip.
 //
 // Replaces, for one batch, the body of the reference's training loops
 //     output = model(data); loss = criterion(output, target); loss.backward()

@@ -1,17 +1,19 @@
-// Split-precision (f16 matrix-core) backward kernels of the LAST convolution of SimpleWakewordModel:
-// the weight gradient and the data gradient of conv2, the two kernels that take 60 % of the exact-fp32 training step.
+// Split-precision (f16 matrix-core) training kernels of the conv stack, both models: device-side weight
+// packing for the forward, and the weight / data gradients of conv2 (2-conv SimpleWakewordModel; dense form for the 3-conv model) and
+// conv3 (3-conv WakewordModel) -- the kernels that took 85 % of the exact-fp32 training step (ww_train.hip).
 //
-// What is computed is the same as in ww_train.hip (/root/reference/wakeword_training/train_wakeword.py:109-115, loss.backward()):
-//     dW2[co][ci][dy][dx] = sum_b gp[b,co] * S[b][co][ci][dy][dx],     S = sum_{y,x} mask[b,co,y,x] * a1[b,ci,y+dy-1,x+dx-1]
-//     da1[b,ci,y,x]       = sum_{co,dy,dx} mask[b,co,y-dy+1,x-dx+1] * (gp[b,co] * W2[co][ci][dy][dx])
-// with mask = [relu(conv2) > 0] and gp = d loss / d pooled / (80 T): the last conv's gradient is rank one, so ONE operand of either
-// product is a 0/1 matrix -- exact in f16.  The other operand (a1, or gp * W2 rebuilt per clip) is carried as two f16 halves
-// (x * 2^-e = hi + lo, 22 bits), every product block is TWO v_mfma_f32_16x16x32_f16 (mask * hi + mask * lo), all products are exact in
-// the fp32 accumulator and gp enters in fp32: the result differs from the exact-fp32 kernels only by the 2^-22 of the split and by
-// the accumulation order.  16x the matrix rate of v_mfma_f32_32x32x2_f32 at 2 instead of 1 instructions per product.
+// What is computed is the same as in ww_train.hip (/root/reference/wakeword_training/train_wakeword.py:109-115,
+// wakeword_training_script.py:250-258: loss.backward()).  For the LAST conv of a model (its ReLU feeds only the global average pool)
+//     dW[co][ci][dy][dx] = sum_b gp[b,co] * S[b][co][ci][dy][dx],     S = sum_{y,x} mask[b,co,y,x] * a[b,ci,y+dy-1,x+dx-1]
+//     da[b,ci,y,x]       = sum_{co,dy,dx} mask[b,co,y-dy+1,x-dx+1] * (gp[b,co] * W[co][ci][dy][dx])
+// with mask = [relu(conv) > 0] and gp = d loss / d pooled / (80 T): the gradient is rank one, so ONE operand of either product is a
+// 0/1 matrix -- exact in f16.  The other operand (the input activations, or gp * W rebuilt per clip) is carried as two f16 halves
+// (x * 2^-e = hi + lo), every product block is TWO v_mfma_f32_16x16x32_f16 (mask * hi + mask * lo), all products are exact in the fp32
+// accumulator and gp enters in fp32.  Below the last conv the gradient is dense: both operands as two halves, three MFMAs per block.
+// The results differ from the exact-fp32 kernels by the 2^-24 of the splits and by the accumulation order (the f16 MFMA rounds the exact
+// 32-term sum once: scripts/ubench/mfma_round.hip).  16x the matrix rate of v_mfma_f32_32x32x2_f32 at 2-3 instructions per product.
 //
-// The mask travels as BITS: maskbits[b][row][col] = COUT bits (bit c of the position's word(s) = [relu(conv)[c] > 0]), 20 KB per clip
-// instead of the 655 KB of the float activations.
+// The masks travel as BITS written by the forward kernels: maskbits[b][row][col] = COUT bits, bits1[b][row][col] = conv1's 32 sign bits.
 #include "ww_conv1.h"
 #include "ww_internal.h"
 
