@@ -431,12 +431,20 @@ __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dg
     }
 }
 
-// out[i] = sum over workgroups g (fixed order) of partial[g][i]
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int groups, int len, float* __restrict__ out) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+// out[i] = sum over workgroups g of partial[g][i] in a fixed order: 256 threads = 64 outputs x 4 slices of the groups (g = 4 q + slice),
+// the four slice sums added in order
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int groups, int len, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (int i0 = blockIdx.x * 64; i0 < len; i0 += gridDim.x * 64) {
+        const int i = i0 + c;
         float s = 0.f;
-        for (int g = 0; g < groups; ++g) s += partial[int64_t(g) * len + i];
-        out[i] = s;
+        if (i < len)
+            for (int g = sl; g < groups; g += 4) s += partial[int64_t(g) * len + i];
+        part[sl][c] = s;
+        __syncthreads();
+        if (sl == 0 && i < len) out[i] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        __syncthreads();
     }
 }
 
@@ -463,24 +471,6 @@ __global__ void lstm_gates_bwd_kernel(const float* __restrict__ dhd, const float
     }
 }
 
-// out[j] = sum_b x[b][j] in a fixed order (bias gradients): 1024 threads = 64 columns x 16 row slices, slices summed through LDS
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ out) {
-    __shared__ float part[16][65];
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (j < cols)
-        for (int b = sl; b < rows; b += 16) s += x[int64_t(b) * cols + j];
-    part[sl][c] = s;
-    __syncthreads();
-    if (sl == 0 && j < cols) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += part[i][c];
-        out[j] = t;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // C[M][N] = sum_k A(m,k) B(k,n) with general strides (the six small GEMMs of the head's backward: M*N*K <= 1.1e9) on
 // v_mfma_f32_32x32x2_f32, exact fp32.  A workgroup of 4 waves owns a 32 x 32 tile of C; wave w takes the k pairs w, w + 4, ...
@@ -488,9 +478,12 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 // (one dword per lane and MFMA for each: A lane = (m, k parity), B lane = (n, k parity)); the four partial tiles are summed
 // through LDS in the fixed order 0, 1, 2, 3.  Rows / columns beyond M / N load zeros and are not stored.
 // ------------------------------------------------------------------------------------------------
+// rowsum (nullable): rowsum[m] = sum_k A(m,k) in the same fixed order -- the bias gradients are the row sums of the weight-gradient GEMMs' A.
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B,
-                                                        int64_t sbk, int64_t sbn, float* __restrict__ C, int64_t ldc, int M, int N, int K) {
+                                                        int64_t sbk, int64_t sbn, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                        float* __restrict__ rowsum) {
     __shared__ float xch[3][16][64];
+    __shared__ float rs[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mn = lane & 31, kk = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -500,6 +493,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict_
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    float asum = 0.f;
     const int pairs = (K + 1) / 2;
     int p = wave;
     for (; p + 28 < pairs; p += 32) {                        // eight k pairs per trip: sixteen loads in flight under the MFMAs
@@ -512,7 +506,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict_
             b[u] = (b_ok && k_ok) ? bp[int64_t(k) * sbk] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0); asum += a[u]; }
     }
     for (; p < pairs; p += 4) {
         const int k = 2 * p + kk;
@@ -520,7 +514,9 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict_
         const float a = (a_ok && k_ok) ? ap[int64_t(k) * sak] : 0.f;
         const float b = (b_ok && k_ok) ? bp[int64_t(k) * sbk] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        asum += a;
     }
+    if (rowsum != nullptr && blockIdx.x == 0) rs[wave][lane] = asum;
     if (wave > 0) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) xch[wave - 1][j][lane] = acc[j];
@@ -533,12 +529,15 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict_
             const int m = m0 + (j & 3) + 8 * (j >> 2) + 4 * kk;          // D: lane & 31 = n, register j <-> row m
             if (m < M && b_ok) C[int64_t(m) * ldc + n0 + mn] = v;
         }
+        if (rowsum != nullptr && blockIdx.x == 0 && lane < 32 && a_ok)        // (wave 0..3) x (k parity 0, 1), fixed order
+            rowsum[m0 + lane] = (((rs[0][lane] + rs[0][lane + 32]) + (rs[1][lane] + rs[1][lane + 32])) + (rs[2][lane] + rs[2][lane + 32])) +
+                                (rs[3][lane] + rs[3][lane + 32]);
     }
 }
 
 static void sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int M, int N, int K,
-                  hipStream_t st) {
-    hipLaunchKernelGGL(mfma_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K);
+                  hipStream_t st, float* rowsum = nullptr) {
+    hipLaunchKernelGGL(mfma_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, rowsum);
 }
 
 // gp[b][co] = dpooled[b][co] / (80 * width)
@@ -678,7 +677,7 @@ int train_forward(const float* mel, int64_t n, int width, const ww_train_params*
 
 // partial[groups][len] -> reduced, then the weight and the bias part go to their gradient tensors
 static int reduce_to(const TrainWs& w, int groups, int len, int w_len, float* dw, float* db, int b_len, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256 < 288 ? (len + 255) / 256 : 288), dim3(256), 0, st, w.partial, groups, len, w.reduced);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 63) / 64 < 1024 ? (len + 63) / 64 : 1024), dim3(256), 0, st, w.partial, groups, len, w.reduced);
     WW_HIP(hipGetLastError());
     WW_HIP(hipMemcpyAsync(dw, w.reduced, sizeof(float) * w_len, hipMemcpyDeviceToDevice, st));
     WW_HIP(hipMemcpyAsync(db, w.reduced + w_len, sizeof(float) * b_len, hipMemcpyDeviceToDevice, st));
@@ -695,19 +694,16 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const int N = int(n), H = kHidden;
     const bool bits = train_math_mode() == WW_TRAIN_MATH_F16X3;       // the forward left bit images (and channels-last relu(conv2))
     const bool split = bits && nc == 2;                               // the kernels of ww_train_h.hip
-    // fc: dW = dlogits^T hd1, db = colsum(dlogits), dhd1 = dlogits W_fc
-    sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(1024), 0, st, dlogits, N, 2, g->fc_bias);
+    // fc: dW = dlogits^T hd1, db = the row sums of dlogits^T, dhd1 = dlogits W_fc
+    sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st, g->fc_bias);
     sgemm(dlogits, 2, 1, p->fc_weight, H, 1, w.dhd1, H, N, H, 2, st);
     // layer 1
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(1024), dim3(256), 0, st, w.dhd1, w.gates1, w.mask1, N, w.dg1);
-    sgemm(w.dg1, 1, 4 * H, w.hd0, H, 1, g->lstm_weight_ih[1], H, 4 * H, H, N, st);             // [1024][256] = dg1^T hd0
-    hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(1024), 0, st, w.dg1, N, 4 * H, g->lstm_bias[1]);
+    sgemm(w.dg1, 1, 4 * H, w.hd0, H, 1, g->lstm_weight_ih[1], H, 4 * H, H, N, st, g->lstm_bias[1]);   // [1024][256] = dg1^T hd0; bias = its A's row sums
     sgemm(w.dg1, 4 * H, 1, p->lstm_weight_ih[1], H, 1, w.dhd0, H, N, H, 4 * H, st);            // [n][256] = dg1 W_ih_l1
     // layer 0
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(1024), dim3(256), 0, st, w.dhd0, w.gates0, w.mask0, N, w.dg0);
-    sgemm(w.dg0, 1, 4 * H, w.pooled, c_last, 1, g->lstm_weight_ih[0], c_last, 4 * H, c_last, N, st);       // [1024][C] = dg0^T pooled
-    hipLaunchKernelGGL(colsum_kernel, dim3(16), dim3(1024), 0, st, w.dg0, N, 4 * H, g->lstm_bias[0]);
+    sgemm(w.dg0, 1, 4 * H, w.pooled, c_last, 1, g->lstm_weight_ih[0], c_last, 4 * H, c_last, N, st, g->lstm_bias[0]);   // [1024][C] = dg0^T pooled
     sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], c_last, 1, w.dpooled, c_last, N, c_last, 4 * H, st);      // [n][C] = dg0 W_ih_l0
     if (bits) {
         if (int rc = launch_gp_max(w.dpooled, 1.0f / float(kTH * width), n, nc, w.gp, w.dgh, st)) return rc;

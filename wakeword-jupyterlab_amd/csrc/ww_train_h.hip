@@ -672,20 +672,30 @@ __global__ __launch_bounds__(768, 3) void conv3_wgrad_h_kernel(const float* __re
     }
 }
 
-// sum of the workgroups' lane-order partials in a fixed order, un-permuted to torch's [128][64][3][3] (+ bias)
-__global__ void reduce_wgrad3_h_kernel(const float* __restrict__ partial, int groups, float* __restrict__ out) {
+// sum of the workgroups' lane-order partials in a fixed order (four slices of the groups per output, added in order), un-permuted to
+// torch's [128][64][3][3] (+ bias).  Thread -> SOURCE index (coalesced reads); the destination follows from it.
+__global__ __launch_bounds__(256) void reduce_wgrad3_h_kernel(const float* __restrict__ partial, int groups, float* __restrict__ out) {
     constexpr int kW = 128 * 64 * 9, kP = kW + 128;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kP; i += gridDim.x * blockDim.x) {
-        int src = i;
-        if (i < kW) {
-            const int t = i % 9, ci = (i / 9) % 64, co = i / (9 * 64);
-            const int hf = co >> 6, ct = (co >> 4) & 3, grp = (co >> 2) & 3, j = co & 3, it = ci >> 4, ln = ci & 15;
-            const int wave = ct + 4 * (it >> 1), u = it & 1;
-            src = ((((hf * 8 + wave) * 18) + u * 9 + t) * 4 + j) * 64 + ln + 16 * grp;
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (int i0 = blockIdx.x * 64; i0 < kP; i0 += gridDim.x * 64) {
+        const int src = i0 + c;
+        float s = 0.f;
+        if (src < kP)
+            for (int g = sl; g < groups; g += 4) s += partial[int64_t(g) * kP + src];
+        part[sl][c] = s;
+        __syncthreads();
+        if (sl == 0 && src < kP) {
+            int dst = src;
+            if (src < kW) {      // src = ((((hf*8 + wave)*18) + u*9 + t)*4 + j)*64 + lane
+                const int lane = src & 63, j = (src >> 6) & 3, ut = (src >> 8) % 18, hw = src / (18 * 256);
+                const int u = ut / 9, t = ut - 9 * u, wave = hw & 7, hf = hw >> 3;
+                const int co = 64 * hf + 16 * (wave & 3) + 4 * (lane >> 4) + j, ci = 16 * (2 * (wave >> 2) + u) + (lane & 15);
+                dst = (co * 64 + ci) * 9 + t;
+            }
+            out[dst] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
         }
-        float sum = 0.f;
-        for (int g = 0; g < groups; ++g) sum += partial[int64_t(g) * kP + src];
-        out[i] = sum;
+        __syncthreads();
     }
 }
 
@@ -1216,7 +1226,7 @@ int launch_conv3_wgrad_h(const float* act2, const float* apow2, const uint32_t* 
     if (int rc = train_h_opt_in()) return rc;
     hipLaunchKernelGGL(conv3_wgrad_h_kernel, dim3(grid), dim3(768), Wg3H::kLds, st, act2, apow2, reinterpret_cast<const uint8_t*>(maskbits), gp,
                        int(n), partial);
-    hipLaunchKernelGGL(reduce_wgrad3_h_kernel, dim3(288), dim3(256), 0, st, partial, grid, reduced);
+    hipLaunchKernelGGL(reduce_wgrad3_h_kernel, dim3(1024), dim3(256), 0, st, partial, grid, reduced);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
