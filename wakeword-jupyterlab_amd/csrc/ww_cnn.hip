@@ -1005,7 +1005,14 @@ constexpr int kW3Plane = kRS * kW3Rec;              // 9,792
 constexpr int kW3Buf = 4 * kW3Plane;                // 39,168
 constexpr int kC3wLds = 2 * kW3Buf;
 
-// BITS (training forward): also bits3[n][80][32] = 128 bits per position, bit c = [relu(conv3)[c] > 0] (8 x uint16, one per N-tile).
+// v_writelane_b32: the wave-uniform value goes into ONE lane of the register (no clang builtin in this toolchain)
+template <int LANE>
+__device__ __forceinline__ uint32_t write_lane(uint32_t uniform_value, uint32_t reg) {
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(uniform_value), "n"(LANE));      // lane select: an inline constant
+    return reg;
+}
+// BITS (training forward): also the ReLU mask of conv3, [relu(conv3) > 0], as the accumulator ballots themselves:
+// bits3[n][40 tile rows][8 N-tiles][2 column halves][2 rows][4 j] x 64 bits (ww_train_h.hip: mask3_byte).
 template <bool BITS>
 __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__ mid, const float* __restrict__ apow2, int n, int width,
                                                        const u32x4* __restrict__ wH, const float* __restrict__ hs,
@@ -1113,14 +1120,22 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
                     live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
                 }
             }
-            if constexpr (BITS) {               // lane (kq, pi < 4) stores the 16 channel bits of column 16 c + 4 kq + pi, both rows
-                const unsigned long long s0 = pi == 0 ? live0[0] : (pi == 1 ? live0[1] : (pi == 2 ? live0[2] : live0[3]));
-                const unsigned long long s1 = pi == 0 ? live1[0] : (pi == 1 ? live1[1] : (pi == 2 ? live1[2] : live1[3]));
-                if (pi < 4) {
+            if constexpr (BITS) {
+                // the eight ballots of (row r, register j) go out as they are: 64 contiguous bytes per (tile row, N-tile, column half) =
+                // [r][j] x 64 bits, bit 16 kq + pi <-> column 16 c + 4 kq + j, channel 16 nt + pi.  v_writelane moves each half into
+                // lane 2 (4 r + j) + half of one register: 16 scalar-to-lane moves and ONE 4-byte store by 16 lanes.
+                uint32_t word = 0u;
+                word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
+                word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
+                word = write_lane<4>(uint32_t(live0[2]), word);  word = write_lane<5>(uint32_t(live0[2] >> 32), word);
+                word = write_lane<6>(uint32_t(live0[3]), word);  word = write_lane<7>(uint32_t(live0[3] >> 32), word);
+                word = write_lane<8>(uint32_t(live1[0]), word);  word = write_lane<9>(uint32_t(live1[0] >> 32), word);
+                word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
+                word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
+                word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
+                if (lane < 16) {
                     const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                    uint16_t* o = bits3 + ((clip * kH + 2 * t) * kW + 16 * c + 4 * kq + pi) * 8 + nt;
-                    o[0] = uint16_t(s0 >> (16 * kq));
-                    o[kW * 8] = uint16_t(s1 >> (16 * kq));
+                    reinterpret_cast<uint32_t*>(bits3)[((((clip * kWTileRows + t) * 8 + nt) * 2 + c) * 16) + lane] = word;
                 }
             }
             // the next tile row goes into the OTHER buffer (last read in step g-1) between the two column halves: its loads have

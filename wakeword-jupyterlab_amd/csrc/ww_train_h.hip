@@ -25,6 +25,12 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr int kTH = WW_N_MELS, kTW = 32;
 
 
+// Byte `cb` (channels 8 cb .. 8 cb + 7) of position (row, col) in conv3's mask image as cnn3w_kernel<true> writes it (its accumulator
+// ballots: [40 tile rows][8 N-tiles][2 column halves][2 rows][4 j] x 64 bits, bit 16 kq + pi <-> column 16 c + 4 kq + j, channel 16 nt + pi)
+__device__ __forceinline__ int64_t mask3_byte(int64_t clip, int row, int col, int cb) {
+    const int t = row >> 1, r = row & 1, nt = cb >> 1, c = col >> 4, kq = (col >> 2) & 3, j = col & 3;
+    return ((((((clip * (kTH / 2) + t) * 8 + nt) * 2 + c) * 2 + r) * 4 + j) * 8) + 2 * kq + (cb & 1);
+}
 // ds_read_b64_tr_b16: within a group of 16 lanes, lane 4q + p supplies the address of row q, 16-bit columns 4p .. 4p+3 of a 4 x 16 block;
 // lane i receives column i, row q in element q (scripts/ubench/tr_read.hip).  EXEC must be all ones.
 __device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
@@ -499,7 +505,7 @@ struct Wg3H {
 static_assert(Wg3H::kLds <= 160 * 1024 && Wg3H::kOffA % 16 == 0 && Wg3H::kOffLut % 16 == 0, "LDS map");
 
 __global__ __launch_bounds__(768, 3) void conv3_wgrad_h_kernel(const float* __restrict__ act2 /*[n][80][32][64]*/, const float* __restrict__ apow2,
-                                                               const uint8_t* __restrict__ maskbits /*[n][80][32][16 bytes]*/,
+                                                               const uint8_t* __restrict__ maskbits /*conv3 mask image: mask3_byte*/,
                                                                const float* __restrict__ gp /*[n][128]*/, int n, float* __restrict__ partial) {
     using L = Wg3H;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(768, 3) void conv3_wgrad_h_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int g = g0 + i;
-            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mcol) * 16 + 8 * hf + mcg] : uint8_t(0);
+            mb[i] = g <= g1 ? maskbits[mask3_byte(clip, g, mcol, 8 * hf + mcg)] : uint8_t(0);
         }
         // relu(conv2) rows 4s .. 4s+3, this thread's column and 8 channels
         const float down = __uint_as_float(0x7f000000u - __float_as_uint(apow2[clip]));       // 2^-a2
@@ -1006,7 +1012,7 @@ __global__ void gp_max128_kernel(const float* __restrict__ dpooled, float s, int
 }
 
 __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __restrict__ act2 /*[n][80][32][64]*/,
-                                                               const uint8_t* __restrict__ maskbits /*[n][80][32][16 bytes]*/,
+                                                               const uint8_t* __restrict__ maskbits /*conv3 mask image: mask3_byte*/,
                                                                const float* __restrict__ gp, const float* __restrict__ gpmax,
                                                                const float* __restrict__ wp, const float* __restrict__ w3max, int n,
                                                                _Float16* __restrict__ dz2h /*[n][80][32][64 hi | 64 lo]*/,
@@ -1042,7 +1048,7 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int g = g0 + i;
-            mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mpos) * 16 + mcg] : uint8_t(0);
+            mb[i] = g <= g1 ? maskbits[mask3_byte(clip, g, mpos, mcg)] : uint8_t(0);
         }
     };
     auto fill_store = [&](int gs) {
