@@ -25,7 +25,18 @@ kp = 64 * 32 * 9 + 64
 take(256 * kp); take(kp)
 mb = take(n * 80 * 32 * 2); take(int(nat.lib.ww_packed_weights_floats(2))); b1 = take(n * 80 * 32)
 bits1 = ws[b1:b1 + n * 80 * 32].reshape(n, 80, 32)
-mask2 = ws[mb:mb + n * 80 * 32 * 2].reshape(n, 80, 32, 2)
+# conv2's mask image = the accumulator ballots: [clip][40 tile rows][4 N-tiles][2 column halves][2 rows][4 j] x 64 bits,
+# bit 16 kq + pi <-> column 16 c + 4 kq + j, channel 16 nt + pi  ->  words [clip][row][col][2]
+raw = ws[mb:mb + n * 80 * 32 * 2].view(np.uint8).reshape(n, 40, 4, 2, 2, 4, 4, 2)       # [.., t, nt, c, r, j, kq, half] bytes
+mask2 = np.zeros((n, 80, 32, 8), np.uint8)
+for t in range(40):
+    for nt in range(4):
+        for c in range(2):
+            for r in range(2):
+                for j in range(4):
+                    for kq in range(4):
+                        mask2[:, 2 * t + r, 16 * c + 4 * kq + j, 2 * nt:2 * nt + 2] = raw[:, t, nt, c, r, j, kq]
+mask2 = np.ascontiguousarray(mask2).view(np.uint32).reshape(n, 80, 32, 2)
 X = torch.from_numpy(x).double()
 z1 = F.conv2d(X, torch.from_numpy(sd["conv1.weight"]).double(), torch.from_numpy(sd["conv1.bias"]).double(), padding=1)
 z2 = F.conv2d(F.relu(z1), torch.from_numpy(sd["conv2.weight"]).double(), torch.from_numpy(sd["conv2.bias"]).double(), padding=1)

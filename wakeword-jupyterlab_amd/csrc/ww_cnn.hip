@@ -647,6 +647,12 @@ extern "C" __attribute__((visibility("default"))) int ww_debug_cnn_stamps(unsign
 }
 #endif
 
+// v_writelane_b32: the wave-uniform value goes into ONE lane of the register (no clang builtin in this toolchain)
+template <int LANE>
+__device__ __forceinline__ uint32_t write_lane(uint32_t uniform_value, uint32_t reg) {
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(uniform_value), "n"(LANE));      // lane select: an inline constant
+    return reg;
+}
 // ------------------------------------------------------------------------------------------------
 // cnn2w_kernel: conv1 + conv2 + ReLU + pool with conv2 as a ONE-DIMENSIONAL WINOGRAD F(2,3) along the image rows
 // (split precision, v_mfma_f32_16x16x32_f16 x3): two output rows (2t, 2t+1) of a "tile row" t come from the four
@@ -684,8 +690,8 @@ static_assert(kWTileRows % 4 == 0, "four producers with equal shares");
 
 // OUT 1 (POOL): out = pooled [n][64].   OUT 0 (3-conv model): out = relu(conv2) as float32 [n][80 rows][32 columns][64 channels] (zero
 // beyond `width`) for cnn3w_kernel, and apow2[clip] = 2^a2, the exponent that kernel gives its transformed conv3 inputs.
-// OUT 2 (training forward of the 2-conv model): pooled as under OUT 1, plus bits[n][80][32] = 64 bits per position,
-// bit c = [relu(conv2)[c] > 0] (as 4 x uint16, one per N-tile), and bits1[n][80][32] = 32 bits per position, bit c = [relu(conv1)[c] > 0]
+// OUT 2 (training forward of the 2-conv model): pooled as under OUT 1, plus the ReLU mask of conv2 as the accumulator ballots themselves,
+// bits[n][40 tile rows][4 N-tiles][2 column halves][2 rows][4 j] x 64 bits (ww_train_h.hip: mask2_byte), and bits1[n][80][32] = 32 bits per position, bit c = [relu(conv1)[c] > 0]
 // (2 x uint16, one per producer half-wave): all the backward pass needs of the activations (ww_train_h.hip).
 // OUT 3 (training forward of the 3-conv model): relu(conv2) and apow2 as under OUT 0, plus bits1.
 template <int OUT>
@@ -949,14 +955,19 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                         live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
                     }
                 }
-                if constexpr (BITS) {           // lane (kq, pi < 4) stores the 16 channel bits of column 16 c + 4 kq + pi, both rows
-                    const unsigned long long s0 = pi == 0 ? live0[0] : (pi == 1 ? live0[1] : (pi == 2 ? live0[2] : live0[3]));
-                    const unsigned long long s1 = pi == 0 ? live1[0] : (pi == 1 ? live1[1] : (pi == 2 ? live1[2] : live1[3]));
-                    if (pi < 4) {
+                if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
+                    uint32_t word = 0u;
+                    word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
+                    word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
+                    word = write_lane<4>(uint32_t(live0[2]), word);  word = write_lane<5>(uint32_t(live0[2] >> 32), word);
+                    word = write_lane<6>(uint32_t(live0[3]), word);  word = write_lane<7>(uint32_t(live0[3] >> 32), word);
+                    word = write_lane<8>(uint32_t(live1[0]), word);  word = write_lane<9>(uint32_t(live1[0] >> 32), word);
+                    word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
+                    word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
+                    word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
+                    if (lane < 16) {
                         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                        uint16_t* o = bits + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + pi) * 4 + nt;
-                        o[0] = uint16_t(s0 >> (16 * kq));
-                        o[kW * 4] = uint16_t(s1 >> (16 * kq));
+                        reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16) + lane] = word;
                     }
                 }
             }
@@ -1005,12 +1016,6 @@ constexpr int kW3Plane = kRS * kW3Rec;              // 9,792
 constexpr int kW3Buf = 4 * kW3Plane;                // 39,168
 constexpr int kC3wLds = 2 * kW3Buf;
 
-// v_writelane_b32: the wave-uniform value goes into ONE lane of the register (no clang builtin in this toolchain)
-template <int LANE>
-__device__ __forceinline__ uint32_t write_lane(uint32_t uniform_value, uint32_t reg) {
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(uniform_value), "n"(LANE));      // lane select: an inline constant
-    return reg;
-}
 // BITS (training forward): also the ReLU mask of conv3, [relu(conv3) > 0], as the accumulator ballots themselves:
 // bits3[n][40 tile rows][8 N-tiles][2 column halves][2 rows][4 j] x 64 bits (ww_train_h.hip: mask3_byte).
 template <bool BITS>

@@ -31,6 +31,11 @@ __device__ __forceinline__ int64_t mask3_byte(int64_t clip, int row, int col, in
     const int t = row >> 1, r = row & 1, nt = cb >> 1, c = col >> 4, kq = (col >> 2) & 3, j = col & 3;
     return ((((((clip * (kTH / 2) + t) * 8 + nt) * 2 + c) * 2 + r) * 4 + j) * 8) + 2 * kq + (cb & 1);
 }
+// the same for conv2's mask image (cnn2w_kernel<2>: four N-tiles)
+__device__ __forceinline__ int64_t mask2_byte(int64_t clip, int row, int col, int cb) {
+    const int t = row >> 1, r = row & 1, nt = cb >> 1, c = col >> 4, kq = (col >> 2) & 3, j = col & 3;
+    return ((((((clip * (kTH / 2) + t) * 4 + nt) * 2 + c) * 2 + r) * 4 + j) * 8) + 2 * kq + (cb & 1);
+}
 // ds_read_b64_tr_b16: within a group of 16 lanes, lane 4q + p supplies the address of row q, 16-bit columns 4p .. 4p+3 of a 4 x 16 block;
 // lane i receives column i, row q in element q (scripts/ubench/tr_read.hip).  EXEC must be all ones.
 __device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(768, 3) void conv2_wgrad_h_kernel(const float* __re
                 dzh[i] = rec[0];
                 dzl[i] = rec[8];
             } else {
-                mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + mcol) * 8 + mcg] : uint8_t(0);
+                mb[i] = g <= g1 ? maskbits[mask2_byte(clip, g, mcol, mcg)] : uint8_t(0);
             }
         }
         if (s == 0) {                                            // the clip's scales: bias in the accumulator's scale, descale
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
-                mb[i] = g <= g1 ? maskbits[((clip * kTH + g) * kTW + (pos & 31)) * 8 + mcg] : uint8_t(0);
+                mb[i] = g <= g1 ? maskbits[mask2_byte(clip, g, pos & 31, mcg)] : uint8_t(0);
             }
         }
         if (tid < kHRows * kTW) sw_next = bits1[(clip * kTH + kHRows * s) * kTW + tid];
