@@ -579,8 +579,11 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     int64_t o = 0;
     auto take = [&](int64_t floats) { float* at = p ? p + o : nullptr; o += a256(floats); return at; };
     const int c_last = n_conv == 3 ? 128 : 64;
-    w.mid2 = take(n * kTH * 64 * kTW);
-    w.mid3 = n_conv == 3 ? take(n * kTH * 128 * kTW) : nullptr;
+    // the activations the exact-fp32 kernels keep; under the split arithmetic only the 3-conv model's relu(conv2) is stored (the rest
+    // travels as bit images), so the layout depends on the arithmetic: query, forward and backward must agree on ww_set_train_math
+    const bool split = train_math_mode() == WW_TRAIN_MATH_F16X3;
+    w.mid2 = (!split || n_conv == 3) ? take(n * kTH * 64 * kTW) : nullptr;
+    w.mid3 = (n_conv == 3 && !split) ? take(n * kTH * 128 * kTW) : nullptr;
     w.dz2 = n_conv == 3 ? take(n * kTH * 64 * kTW) : nullptr;
     w.pooled = take(n * c_last);
     w.gates0 = take(4 * n * kHidden); w.mask0 = take(n * kHidden); w.hd0 = take(n * kHidden);

@@ -14,6 +14,8 @@
 // 32-term sum once: scripts/ubench/mfma_round.hip).  16x the matrix rate of v_mfma_f32_32x32x2_f32 at 2-3 instructions per product.
 //
 // The masks travel as BITS written by the forward kernels: maskbits[b][row][col] = COUT bits, bits1[b][row][col] = conv1's 32 sign bits.
+#include <mutex>
+
 #include "ww_conv1.h"
 #include "ww_internal.h"
 
@@ -1193,7 +1195,9 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int train_h_opt_in() {
+    static std::mutex mu;
     static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     WW_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(WW_EINVAL, "device ordinal out of range");
