@@ -733,7 +733,7 @@ struct DgHT {
     static constexpr int CIN = 32, COUT = 64;
     static constexpr int kGRec = DENSE ? 288 : 160, kGRow = 34 * kGRec;     // columns -1..32, conflict-free 16-byte row reads
     static constexpr int kMelRS = 36, kMelFloats = (kTH + 2) * kMelRS;      // fp32 log-mel tile with a zero halo
-    static constexpr int kOffMel = kHGRing * kGRow;
+    static constexpr int kOffMel = (kHGRing + 1) * kGRow;                   // ring + one all-zero row (the rows above / below the image)
     static constexpr int kOffS1 = kOffMel + 2 * kMelFloats * 4;             // conv1 sign words: 2 steps x 4 rows x 32 columns
     static constexpr int kOffLut = kOffS1 + 2 * kHRows * kTW * 4;
     static constexpr int kLds = kOffLut + 256 * 16;
@@ -910,28 +910,39 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[mt][j] = 0.f;
+        // 36 fragment steps it = ((dy*3 + dx)*2 + kb)*2 + mt; the fragments run PF steps ahead of their MFMAs in a pinned register ring
+        // (left alone the compiler hoists dozens of the 36 loads at once and spills).  A mask row outside the image reads the ring's
+        // all-zero eleventh row: no branch in the stream.
+        const char* rowp[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const int yy = y + 1 - dy;                              // mask row of tap dy
-            if (yy >= 0 && yy < kTH) {                              // wave-uniform
-                const char* rowp = abase + ((k * kTH + yy) % kHGRing) * L::kGRow;
+            const int yy = y + 1 - dy;                              // gradient row of tap dy
+            rowp[dy] = abase + ((yy >= 0 && yy < kTH) ? (k * kTH + yy) % kHGRing : kHGRing) * L::kGRow;
+        }
+        auto frag = [&](int it, int half) -> half8 {
+            const int mt = it & 1, kb = (it >> 1) & 1, tp = it >> 2, dy = tp / 3, dx = tp - 3 * dy;
+            return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp[dy] + (16 * mt + 1 - dx) * L::kGRec + half * 128 + kb * 64));
+        };
+        constexpr int PF = 3, RING = PF + 1;
+        half8 fh[RING], fl[DENSE ? RING : 1];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
+        for (int i = 0; i < PF; ++i) {
+            fh[i] = frag(i, 0);
+            if constexpr (DENSE) fl[i] = frag(i, 1);
+        }
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-                        const int ks = (dy * 3 + dx) * 2 + kb;
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            const half8 a = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp + (16 * mt + 1 - dx) * L::kGRec + kb * 64));
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[ks], acc[mt], 0, 0, 0);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl[ks], acc[mt], 0, 0, 0);
-                            if constexpr (DENSE) {
-                                const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp + (16 * mt + 1 - dx) * L::kGRec + 128 + kb * 64));
-                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc[mt], 0, 0, 0);
-                            }
-                        }
-                    }
+        for (int it = 0; it < 36; ++it) {
+            if (it + PF < 36) {
+                fh[(it + PF) % RING] = frag(it + PF, 0);
+                if constexpr (DENSE) fl[(it + PF) % RING] = frag(it + PF, 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const int mt = it & 1, ks = it >> 1;
+            const half8 a = fh[it % RING];
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[ks], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl[ks], acc[mt], 0, 0, 0);
+            if constexpr (DENSE) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[it % RING], bh[ks], acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue: D register j <-> column 16 mt + 4 grp + j, lane & 15 <-> ci = 16 nt + ln
         const float* melt = meltile + (k & 1) * L::kMelFloats;
