@@ -923,7 +923,10 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
             const int mt = it & 1, kb = (it >> 1) & 1, tp = it >> 2, dy = tp / 3, dx = tp - 3 * dy;
             return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(rowp[dy] + (16 * mt + 1 - dx) * L::kGRec + half * 128 + kb * 64));
         };
-        constexpr int PF = 3, RING = PF + 1;
+#ifndef WW_DG_PF
+#define WW_DG_PF 3
+#endif
+        constexpr int PF = WW_DG_PF, RING = PF + 1;
         half8 fh[RING], fl[DENSE ? RING : 1];
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
