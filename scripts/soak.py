@@ -4,6 +4,7 @@ result for that input (the kernels are deterministic), plus ww_sync_timeouts(). 
 
     --what forward   the whole PCM -> logits forward on five (arch, batch) cases                     (default)
     --what stages    K1, K2, K3 each alone: localises a rare difference to a stage and to clips
+    --what train     the training step of both models (split-precision kernels), logits + every gradient
     --what conv3     the 3-conv stack with its HBM intermediate poisoned between runs (0x00 / 0xff / 0x7b): separates
                      "conv2 wrote something else" from "conv3 read something stale", back-to-back launches included
 
@@ -113,16 +114,48 @@ def soak_conv3(seconds):
     return out
 
 
+def soak_train(seconds):
+    """The training step (split-precision kernels: barrier-per-step rings, wave-pair exchanges, global read-modify-write partials):
+    the same step with the same dropout seed over and over, logits and every gradient compared bitwise with the first run."""
+    import torch.nn.functional as F
+    cases = []
+    for arch, B, T in (("simple", 300, 32), ("simple", 4096, 32), ("full", 260, 31), ("full", 1024, 32), ("simple", 37, 31)):
+        sd = pkg.synth.make_state_dict(arch, seed=7)
+        m = (pkg.SimpleWakewordModel() if arch == "simple" else pkg.WakewordModel())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m = m.to(dev).train()
+        x = (torch.randn(B, 1, 80, T, device=dev) * 15 - 35).clamp_(-80, 0)
+        y = torch.randint(0, 2, (B,), device=dev)
+
+        def step(m=m, x=x, y=y):
+            m.zero_grad()
+            torch.manual_seed(5)
+            out = m(x)
+            F.cross_entropy(out, y).backward()
+            return [out.detach().clone()] + [p.grad.clone() for p in m.parameters()]
+        cases.append((arch, B, step, step()))
+    torch.cuda.synchronize()
+    t0, steps, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        for arch, B, step, ref in cases:
+            for _ in range(5):
+                got = step()
+                bad += any(not torch.equal(a, b) for a, b in zip(got, ref))
+                steps += 1
+        print("t=%.0fs steps=%d mismatches=%d" % (time.time() - t0, steps, bad), flush=True)
+    return {"train_steps": steps, "mismatches": bad, "cases": [(a, b) for a, b, *_ in cases], "train_math": ops.get_train_math()}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="forward", choices=["forward", "stages", "conv3"])
+    ap.add_argument("--what", default="forward", choices=["forward", "stages", "conv3", "train"])
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--conv-math", default=None, choices=["f32", "f16x3", "f16x3d"])
     args = ap.parse_args()
     if args.conv_math:
         ops.set_conv_math(args.conv_math)
     t0 = time.time()
-    res = {"forward": soak_forward, "stages": soak_stages, "conv3": soak_conv3}[args.what](args.seconds)
+    res = {"forward": soak_forward, "stages": soak_stages, "conv3": soak_conv3, "train": soak_train}[args.what](args.seconds)
     res.update(what=args.what, conv_math=ops.get_conv_math(), seconds=time.time() - t0, sync_timeouts=int(nat.lib.ww_sync_timeouts()))
     print(json.dumps(res))
     sys.exit(1 if res["mismatches"] or res["sync_timeouts"] else 0)
