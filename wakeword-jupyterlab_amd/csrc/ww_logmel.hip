@@ -288,6 +288,8 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
                 const float4 s = sn[n1];
 #if WW_K1_RESIDENT
                 const float4 w = wres[n1];
+#elif defined(WW_K1_ABL_NOTAB)      // timing-only ablation: no window / pass-1 twiddle loads (results are garbage)
+                const float4 w = make_float4(0.5f, 0.25f, 0.75f, 1.0f);
 #else
                 const float4 w = win4[64 * n1 + lane];
 #endif
@@ -303,6 +305,8 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
 #pragma unroll
 #if WW_K1_RESIDENT
             for (int k1 = 1; k1 < 8; ++k1) t1[k1 - 1] = t1res[k1 - 1];
+#elif defined(WW_K1_ABL_NOTAB)
+            for (int k1 = 1; k1 < 8; ++k1) t1[k1 - 1] = make_float4(0.7f, -0.7f, 0.6f, -0.8f);
 #else
             for (int k1 = 1; k1 < 8; ++k1) t1[k1 - 1] = tw1_4[(k1 - 1) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
