@@ -284,7 +284,8 @@ WW_API int ww_train_packed_image(const void* workspace_dev, int64_t n, int32_t n
  *                        is the 0/1 mask, exact in f16, the other is carried as two f16 halves; below it both operands as two halves;
  *                        conv1's weight gradient in double on the f64 matrix instructions.  The head runs as under F32.
  *                        Gradients agree with F32 to the 2^-22 of the split.  A step's workspace query, forward and backward must run under
- *                        the same mode (the workspace layout depends on it: 0.23 GB instead of 2.7 GB for 4096 clips of the 2-conv model). */
+ *                        the same mode (the workspace layout depends on it: 0.23 GB instead of 2.7 GB for 4096 clips of the 2-conv model);
+ *                        ww_train_backward_f32 returns WW_EINVAL for a workspace whose forward ran under the other mode. */
 #define WW_TRAIN_MATH_F32 0
 #define WW_TRAIN_MATH_F16X3 1
 WW_API int ww_set_train_math(int mode);

@@ -573,7 +573,27 @@ struct TrainWs {
     int64_t total;
 };
 static int64_t a256(int64_t floats) { return (floats * 4 + 255) / 256 * 64; }      // floats, 256-byte granules
-static TrainWs carve_train(void* base, int64_t n, int n_conv) {
+// Which arithmetic wrote a workspace: the layout and the meaning of its contents follow the forward's mode, so the backward (and the
+// diagnostics) of a step must not run under another one.  Host-side note per workspace pointer, written by train_forward; a backward
+// under a different mode fails with WW_EINVAL instead of reading bit images that are not there.  (Bounded: the newest 64 workspaces.)
+static std::mutex g_ws_mu;
+static struct { const void* ws; int mode; } g_ws_mode[64];
+static int g_ws_next = 0;
+static void note_workspace_mode(const void* ws, int mode) {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (auto& e : g_ws_mode)
+        if (e.ws == ws) { e.mode = mode; return; }
+    g_ws_mode[g_ws_next] = {ws, mode};
+    g_ws_next = (g_ws_next + 1) % 64;
+}
+static int workspace_mode(const void* ws) {            // -1: unknown (never seen, or evicted)
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (auto& e : g_ws_mode)
+        if (e.ws == ws && ws != nullptr) return e.mode;
+    return -1;
+}
+
+static TrainWs carve_train(void* base, int64_t n, int n_conv, int mode = -1) {
     TrainWs w{};
     float* p = static_cast<float*>(base);
     int64_t o = 0;
@@ -581,7 +601,7 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv) {
     const int c_last = n_conv == 3 ? 128 : 64;
     // the activations the exact-fp32 kernels keep; under the split arithmetic only the 3-conv model's relu(conv2) is stored (the rest
     // travels as bit images), so the layout depends on the arithmetic: query, forward and backward must agree on ww_set_train_math
-    const bool split = train_math_mode() == WW_TRAIN_MATH_F16X3;
+    const bool split = (mode >= 0 ? mode : train_math_mode()) == WW_TRAIN_MATH_F16X3;
     w.mid2 = (!split || n_conv == 3) ? take(n * kTH * 64 * kTW) : nullptr;
     w.mid3 = (n_conv == 3 && !split) ? take(n * kTH * 128 * kTW) : nullptr;
     w.dz2 = n_conv == 3 ? take(n * kTH * 64 * kTW) : nullptr;
@@ -629,7 +649,7 @@ static int train_opt_in() {
 
 // test / diagnostic: copies of the dropout factors the last forward on this workspace drew ([n][256] each)
 int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, float* mask1, hipStream_t st) {
-    TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv);
+    TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv, workspace_mode(workspace));
     WW_HIP(hipMemcpyAsync(mask0, w.mask0, sizeof(float) * n * kHidden, hipMemcpyDeviceToDevice, st));
     WW_HIP(hipMemcpyAsync(mask1, w.mask1, sizeof(float) * n * kHidden, hipMemcpyDeviceToDevice, st));
     return WW_OK;
@@ -637,7 +657,8 @@ int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, floa
 
 // test / diagnostic: the packed image the last split-precision forward of the 2-conv model wrote on the device
 int train_packed_image(const void* workspace, int64_t n, int n_conv, float* img, hipStream_t st) {
-    TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv);
+    if (workspace_mode(workspace) == WW_TRAIN_MATH_F32) return fail(WW_EINVAL, "this workspace's forward ran in exact fp32: no packed image");
+    TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv, workspace_mode(workspace));
     WW_HIP(hipMemcpyAsync(img, w.wpk, sizeof(float) * packed_layout(n_conv).total, hipMemcpyDeviceToDevice, st));
     return WW_OK;
 }
@@ -647,6 +668,7 @@ int train_forward(const float* mel, int64_t n, int width, const ww_train_params*
     if (device_cu_count() > kMaxGroups) return fail(WW_EUNSUPPORTED, "more than 256 CUs: the workspace is sized for 256 partials");
     const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
     TrainWs w = carve_train(workspace, n, nc);
+    note_workspace_mode(workspace, train_math_mode());
     if (train_math_mode() == WW_TRAIN_MATH_F16X3) {
         // split precision: the inference kernels (convs as 1-D Winograd on the f16 matrix cores) with the ReLU masks as extra outputs.
         // 2 convs: relu(conv2) itself is never stored.  3 convs: relu(conv2) stays as float32 [row][column][64].
@@ -693,6 +715,9 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
     const int cus = device_cu_count();
     const int grid = int(n < cus ? n : cus);         // one persistent workgroup per CU (117-149 KB of LDS each)
+    if (const int fwd = workspace_mode(workspace); fwd >= 0 && fwd != train_math_mode())
+        return fail(WW_EINVAL, "the forward of this workspace ran under train math %d, the backward is asked under %d: set the same mode "
+                               "(ww_set_train_math) for both halves of a step", fwd, train_math_mode());
     TrainWs w = carve_train(workspace, n, nc);
     const int N = int(n), H = kHidden;
     const bool bits = train_math_mode() == WW_TRAIN_MATH_F16X3;       // the forward left bit images (and channels-last relu(conv2))
