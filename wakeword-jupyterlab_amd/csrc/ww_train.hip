@@ -743,7 +743,7 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const float* w1 = p->conv_weight[0];
     const float* b1 = p->conv_bias[0];
     if (nc == 3) {
-        hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(288), dim3(256), 0, st, p->conv_weight[2], 128, 64, w.dgrad3_b_op);
+        if (!bits) hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(288), dim3(256), 0, st, p->conv_weight[2], 128, 64, w.dgrad3_b_op);
         if (bits) {
             if (int rc = launch_conv3_wgrad_h(w.mid2, w.apow2, w.maskbits, w.gp, n, w.partial, w.reduced, grid, st)) return rc;
             WW_HIP(hipMemcpyAsync(g->conv_weight[2], w.reduced, sizeof(float) * 128 * 64 * 9, hipMemcpyDeviceToDevice, st));
@@ -761,7 +761,7 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
                                mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.dgrad3_b_op, w.dz2);
         WW_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], 64, 32, w.dgrad2_b_op);
+    if (!bits) hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(72), dim3(256), 0, st, p->conv_weight[1], 64, 32, w.dgrad2_b_op);
     if (nc == 3 && bits) {
         if (int rc = launch_conv2_wgrad_h_dense(mel, w.dz2, dgrad_h_dzs(w.dgh, n), n, width, w.wpk, w.partial, grid, st)) return rc;
     } else if (nc == 3)
