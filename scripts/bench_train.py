@@ -58,6 +58,9 @@ def measure(batch=4096, steps=5, device=0, cpu_sample=64, arch="simple", math=No
                          "(csrc/ww_train_h.hip, ww_train.hip)" if math == "f16x3" else "exact fp32 kernels (csrc/ww_train.hip)"),
             "train_math": math,
             "ms_per_step": dt * 1e3, "clips_per_s": batch / dt, "final_loss": float(loss.item()),
+            # forward + data gradient + weight gradient = 3 x the forward's algorithmic flops (96.5 / 474 MFLOP per clip); the
+            # step also holds the optimiser and torch's loss, so this is a floor for the kernels' own rate
+            "algorithmic_TFLOPs": 3 * (96.5e6 if arch == "simple" else 474.0e6) * batch / dt / 1e12,
             "cpu_torch_clips_per_s": cpu_sample / dt_cpu, "cpu_threads": int(torch.get_num_threads()), "cpu_sample": cpu_sample}
 
 
