@@ -18,10 +18,12 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   cpu_baseline  the CPU oracle (numpy log-mel per clip + torch CPU Conv2d/LSTM/Linear) timed on this
                 host on a bounded sample of the same clips (rank 0, N = 1 only)
   sustained     >= 2 s of back-to-back steps after the timed region (the driver's K steps last ~20 ms: too short to show the
-                clock the chip holds under load): clips/s and per-kernel means over that leg
+                clock the chip holds under load): clips/s and per-kernel means over that leg; `timed_region_again` = the same K steps
+                timed once more right behind it (the K-step figure at the settled clock; `value` stays the cold run's)
   parity        max |err| of the measured path against that oracle on the sample
   augmentation  augment_audio on the GPU: clips/s for plans drawn like the reference, error vs the oracle
-  training      SURVEY 8(f).3: training step of SimpleWakewordModel at the same batch (train-mode forward + backward + Adam)
+  training      SURVEY 8(f).3: training step of SimpleWakewordModel at the same batch (train-mode forward + backward + Adam), both
+                arithmetics; training_pipeline: augment -> log-mel -> step; training_3conv: the notebook's 3-conv model
   streaming     BASELINE configs[4] (256 microphones, 10 ms hop, hipGraph replay per hop): p50/p99 hop latency, hops/s
                 (rank 0, N = 1 only; measured after the timed region)
 """
@@ -253,6 +255,18 @@ def main():
                      "ms_per_step": 1e3 * sus_elapsed / n_sus,
                      "kernel_ms_second_half": dict(zip(["K1", "K2", "K3"], [float(v) for v in sms.mean(axis=0)])),
                      "note": "host-timed, barrier + synchronize on both sides, same step as the timed region"}
+        # ... and the timed region once more, EXACTLY K steps, straight behind the sustained leg: the K-step figure at the settled clock
+        # (reported beside `value`, which stays the cold run's)
+        t2 = time.perf_counter()
+        for k in range(args.steps):
+            step()
+        fence()
+        again = time.perf_counter() - t2
+        ta = torch.tensor([again], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        sustained["timed_region_again"] = {"steps": args.steps, "ms_per_step": 1e3 * float(ta.item()) / args.steps,
+                                           "clips_per_s_per_gpu": B * args.steps / float(ta.item())}
 
     # the float64 log-mel kernel on the whole batch (what auto mode costs per clip it redoes), outside the timed region
     k1_f64_ms = None
@@ -344,6 +358,7 @@ def main():
         }
         if sustained is not None:
             sustained["clips_per_s"] = sustained.pop("clips_per_s_per_gpu") * world
+            sustained["timed_region_again"]["clips_per_s"] = sustained["timed_region_again"].pop("clips_per_s_per_gpu") * world
             out["sustained"] = sustained
         if k2_f32_ms is not None:
             out["roofline_f32_exact"] = {
