@@ -13,7 +13,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All launch
  *     functions are asynchronous on that stream, allocate nothing, never synchronise and are
  *     therefore capturable into a hipGraph once ww_init() has run on the device (exception, stated
- *     at the function: ww_augment_f32 reads its plans from host memory and is not capturable).
+ *     at the function: ww_augment_f32 reads its plans from host memory and is not capturable; its two-call form
+ *     ww_augment_plans_prepare + ww_augment_records_f32 is).
  *   - return value: WW_OK (0) or a negative WW_E* code; ww_last_error() gives the message of the
  *     calling thread's most recent failure.  Nothing falls back to a CPU path: without a usable
  *     gfx950 device every launch function fails with WW_ENODEVICE.
@@ -166,6 +167,15 @@ WW_API int64_t ww_augment_workspace_bytes(int64_t n_clips);
  * workspace_dev >= ww_augment_workspace_bytes(n_clips), 256-byte aligned. */
 WW_API int ww_augment_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, const ww_augment_plan* plans_host,
                    float* out_dev, void* workspace_dev, ww_stream_t stream);
+/* The same in two halves, for hipGraph capture: ww_augment_plans_prepare turns the plans into the fixed-size records the kernels read
+ * (host arithmetic only: [n_clips] x ww_augment_record_bytes() bytes, e.g. into pinned memory), ww_augment_records_f32 is nothing but
+ * kernel launches on `stream` reading the records from DEVICE memory -- capturable; both transform stages are always launched (a clip
+ * whose plan switches one off is copied through it).  A captured step = {copy records host -> device, ww_augment_records_f32};
+ * before every replay: ww_augment_plans_prepare into the host buffer.  Results equal ww_augment_f32's bit for bit. */
+WW_API int64_t ww_augment_record_bytes(void);
+WW_API int ww_augment_plans_prepare(const ww_augment_plan* plans_host, int64_t n_clips, void* records_host);
+WW_API int ww_augment_records_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, const void* records_dev, float* out_dev,
+                                  void* workspace_dev, ww_stream_t stream);
 /* The resampler's half-window (32769 floats: 64 zero crossings x 512 + 1) on the host, for checking on a CPU. */
 WW_API int ww_kaiser_best_host(float* out_host);
 

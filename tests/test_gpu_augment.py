@@ -107,6 +107,52 @@ def test_full_plans_mixed_batch():
         _check(got[i], ao.augment(x[i], plans[i]), max_rel=6e-3, rms_rel=2e-3)    # two vocoder passes in sequence
 
 
+def test_two_call_form_is_graph_capturable_and_bitwise_equal():
+    """ww_augment_plans_prepare (host arithmetic) + ww_augment_records_f32 (kernels only): captured ONCE into a graph together with
+    the host -> device copy of the records, replayed with new plans -- every replay equals ww_augment_f32 on the same plans bit for
+    bit, including a batch where no clip asks for pitch (the captured graph still launches that stage: copy-through)."""
+    import ctypes as C
+    n = 10
+    x = torch.from_numpy(np.ascontiguousarray(_clips(n, start=40), dtype=np.float32)).to(DEV)
+    rb = int(nat.lib.ww_augment_record_bytes())
+    rec_host = torch.empty(n * rb, dtype=torch.uint8).pin_memory()
+    rec_dev = torch.empty(n * rb, dtype=torch.uint8, device=DEV)
+    out = torch.empty_like(x)
+    ws = torch.empty(int(nat.lib.ww_augment_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+
+    def plans_array(plans):
+        arr = (nat.AugmentPlan * n)()
+        for a, p in zip(arr, plans):
+            a.shift, a.crop_start = p["shift"], p["crop"]
+            a.pitch_rate = 2.0 ** (-p["n_steps"] / 12.0) if p["n_steps"] is not None else 0.0
+            a.stretch_rate = p["rate"] or 0.0
+            a.noise_sigma, a.noise_seed = p["sigma"], p["seed"]
+        return arr
+    rng = random.Random(77)
+    batches = [[ao.draw_plan(rng) for _ in range(n)] for _ in range(3)]
+    batches.append([dict(p, n_steps=None) for p in batches[0]])                       # nobody asks for pitch
+    ops.init()
+    nat.check(nat.lib.ww_augment_plans_prepare(C.cast(plans_array(batches[0]), C.c_void_p), n, C.c_void_p(rec_host.data_ptr())))
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                                      # warm-up outside capture (LDS opt-in, tables)
+        rec_dev.copy_(rec_host, non_blocking=True)
+        nat.check(nat.lib.ww_augment_records_f32(x.data_ptr(), n, 16000, rec_dev.data_ptr(), out.data_ptr(), ws.data_ptr(), C.c_void_p(side.cuda_stream)))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        rec_dev.copy_(rec_host, non_blocking=True)
+        nat.check(nat.lib.ww_augment_records_f32(x.data_ptr(), n, 16000, rec_dev.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for plans in batches:
+        nat.check(nat.lib.ww_augment_plans_prepare(C.cast(plans_array(plans), C.c_void_p), n, C.c_void_p(rec_host.data_ptr())))
+        g.replay()
+        torch.cuda.synchronize()
+        want = ops.augment(x, plans_array(plans))
+        assert torch.equal(out, want)
+
+
 def test_rejects_bad_plans_before_launching():
     x = torch.zeros((1, 16000), device=DEV)
     for bad, code in ((dict(OFF, rate=0.5), nat.WW_EUNSUPPORTED), (dict(OFF, rate=40.0), nat.WW_EUNSUPPORTED),

@@ -96,6 +96,9 @@ PROTOTYPES = {
     "ww_decode_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "ww_augment_workspace_bytes": (C.c_int64, [C.c_int64]),
     "ww_augment_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(AugmentPlan), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ww_augment_record_bytes": (C.c_int64, []),
+    "ww_augment_plans_prepare": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "ww_augment_records_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_kaiser_best_host": (C.c_int, [C.c_void_p]),
     "ww_logmel_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "ww_packed_weights_floats": (C.c_int64, [C.c_int32]),

@@ -261,6 +261,27 @@ int ww_augment_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, c
     return launch_augment(pcm_dev, n_clips, clip_stride, plans_host, out_dev, kClip, workspace_dev, static_cast<hipStream_t>(stream));
 }
 
+int64_t ww_augment_record_bytes(void) { return augment_record_bytes(); }
+
+int ww_augment_plans_prepare(const ww_augment_plan* plans_host, int64_t n_clips, void* records_host) {
+    if (n_clips < 0 || n_clips > (int64_t(1) << 24)) return fail(WW_EINVAL, "n_clips %lld out of range", (long long)n_clips);
+    if (n_clips == 0) return WW_OK;
+    if (!plans_host || !records_host) return fail(WW_EINVAL, "null plan / record pointer");
+    return augment_prepare(plans_host, n_clips, records_host, nullptr, nullptr);
+}
+
+int ww_augment_records_f32(const float* pcm_dev, int64_t n_clips, int64_t clip_stride, const void* records_dev, float* out_dev,
+                           void* workspace_dev, ww_stream_t stream) {
+    if (n_clips > (int64_t(1) << 24)) return fail(WW_EINVAL, "n_clips %lld out of range", (long long)n_clips);
+    if (int rc = check_pcm(pcm_dev, n_clips, clip_stride, kClip)) return rc;
+    if (n_clips == 0) return WW_OK;
+    if (!records_dev || !out_dev || !workspace_dev) return fail(WW_EINVAL, "null record / output / workspace pointer");
+    if ((reinterpret_cast<uintptr_t>(out_dev) & 15) || (reinterpret_cast<uintptr_t>(workspace_dev) & 255) || (reinterpret_cast<uintptr_t>(records_dev) & 7))
+        return fail(WW_EINVAL, "out_dev must be 16-byte, workspace_dev 256-byte and records_dev 8-byte aligned");
+    if (int rc = require_gfx950()) return rc;
+    return launch_augment_records(pcm_dev, n_clips, clip_stride, records_dev, true, true, out_dev, kClip, workspace_dev, static_cast<hipStream_t>(stream));
+}
+
 int64_t ww_cnn_scratch_bytes(int64_t n, int32_t n_conv) { return cnn_scratch_bytes(n, n_conv); }
 
 int ww_cnn_pool_f32(const float* mel_dev, int64_t n, int32_t width, const float* packed_dev, int32_t n_conv,

@@ -323,13 +323,9 @@ static std::mutex g_stage_mu;
 static PlanStage g_stage[16][2];
 static int g_stage_next[16] = {};
 
-int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment_plan* plans_host, float* out,
-                   int64_t out_stride, void* workspace, hipStream_t stream) {
-    if (n == 0) return WW_OK;
-    const LogmelTables* tb = device_tables();
-    if (!tb) return WW_EHIP;
-    // derive the per-clip records (librosa's lengths are host arithmetic: len(np.arange), round, ceil)
-    std::vector<AugDev> host(static_cast<size_t>(n));
+// plans -> the per-clip records the kernels read (librosa's lengths are host arithmetic: len(np.arange), round, ceil)
+int augment_prepare(const ww_augment_plan* plans_host, int64_t n, void* records_host, int* any_pitch_out, int* any_stretch_out) {
+    AugDev* host = static_cast<AugDev*>(records_host);
     bool any_pitch = false, any_stretch = false;
     for (int64_t c = 0; c < n; ++c) {
         const ww_augment_plan& p = plans_host[c];
@@ -365,44 +361,40 @@ int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment
             d.crop = p.crop_start;
             any_stretch = true;
         }
-        host[size_t(c)] = d;
+        host[c] = d;
     }
+    if (any_pitch_out) *any_pitch_out = any_pitch;
+    if (any_stretch_out) *any_stretch_out = any_stretch;
+    return WW_OK;
+}
+int64_t augment_record_bytes() { return int64_t(sizeof(AugDev)); }
+
+// The kernels alone, on records already in device memory: nothing but launches on `stream` (capturable into a hipGraph).  A stage whose
+// flag is off for a clip copies that clip through, so both stages may always be launched (what a captured graph must do).
+int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const void* records_dev, bool any_pitch, bool any_stretch, float* out,
+                           int64_t out_stride, void* workspace, hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    const LogmelTables* tb = device_tables();
+    if (!tb) return WW_EHIP;
+    const AugDev* plan = static_cast<const AugDev*>(records_dev);
     char* w = static_cast<char*>(workspace);
-    AugDev* plan = reinterpret_cast<AugDev*>(w); w += up256(n * int64_t(sizeof(AugDev)));
+    w += up256(n * int64_t(sizeof(AugDev)));                        // (the slot ww_augment_f32 copies its records into)
     float* bufA = reinterpret_cast<float*>(w); w += up256(n * int64_t(kClip) * 4);
     float* bufB = reinterpret_cast<float*>(w); w += up256(n * int64_t(kClip) * 4);
     float2* D = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugFrames) * kSpec * 8);
     float2* S = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugMaxOut) * kSpec * 8);
     float* Y = reinterpret_cast<float*>(w);
     {
+        static std::mutex mu;
+        static bool attr[64] = {};
+        std::lock_guard<std::mutex> lock(mu);
         int dev = 0;
         WW_HIP(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 16) return fail(WW_EUNSUPPORTED, "device ordinal %d out of range", dev);
-        std::lock_guard<std::mutex> lock(g_stage_mu);
-        PlanStage& st = g_stage[dev][g_stage_next[dev]];
-        g_stage_next[dev] ^= 1;
-        if (st.in_use) WW_HIP(hipEventSynchronize(st.ev));          // the copy that last read this slot (two calls ago) must be done
-        if (st.cap < size_t(n)) {
-            if (st.host) WW_HIP(hipHostFree(st.host));
-            st.host = nullptr;
-            st.cap = 0;
-            WW_HIP(hipHostMalloc(reinterpret_cast<void**>(&st.host), size_t(n) * sizeof(AugDev), hipHostMallocDefault));
-            st.cap = size_t(n);
+        if (dev >= 0 && dev < 64 && !attr[dev]) {
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIstftLds));
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (kKbLen + 3) * 4));
+            attr[dev] = true;
         }
-        if (!st.ev) WW_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
-        std::memcpy(st.host, host.data(), size_t(n) * sizeof(AugDev));
-        WW_HIP(hipMemcpyAsync(plan, st.host, size_t(n) * sizeof(AugDev), hipMemcpyHostToDevice, stream));
-        WW_HIP(hipEventRecord(st.ev, stream));
-        st.in_use = true;
-    }
-
-    static bool attr[64] = {};
-    int dev = 0;
-    WW_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr[dev]) {
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIstftLds));
-        WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (kKbLen + 3) * 4));
-        attr[dev] = true;
     }
     const dim3 egrid((kClip + 255) / 256, unsigned(n));
     hipLaunchKernelGGL(roll_kernel, egrid, dim3(256), 0, stream, pcm, stride, plan, bufA);
@@ -425,6 +417,37 @@ int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment
     hipLaunchKernelGGL(noise_kernel, egrid, dim3(256), 0, stream, cur, plan, out, out_stride);
     WW_HIP(hipGetLastError());
     return WW_OK;
+}
+
+int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment_plan* plans_host, float* out,
+                   int64_t out_stride, void* workspace, hipStream_t stream) {
+    if (n == 0) return WW_OK;
+    std::vector<AugDev> host(static_cast<size_t>(n));
+    int any_pitch = 0, any_stretch = 0;
+    if (int rc = augment_prepare(plans_host, n, host.data(), &any_pitch, &any_stretch)) return rc;
+    AugDev* plan = reinterpret_cast<AugDev*>(workspace);
+    {
+        int dev = 0;
+        WW_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16) return fail(WW_EUNSUPPORTED, "device ordinal %d out of range", dev);
+        std::lock_guard<std::mutex> lock(g_stage_mu);
+        PlanStage& st = g_stage[dev][g_stage_next[dev]];
+        g_stage_next[dev] ^= 1;
+        if (st.in_use) WW_HIP(hipEventSynchronize(st.ev));          // the copy that last read this slot (two calls ago) must be done
+        if (st.cap < size_t(n)) {
+            if (st.host) WW_HIP(hipHostFree(st.host));
+            st.host = nullptr;
+            st.cap = 0;
+            WW_HIP(hipHostMalloc(reinterpret_cast<void**>(&st.host), size_t(n) * sizeof(AugDev), hipHostMallocDefault));
+            st.cap = size_t(n);
+        }
+        if (!st.ev) WW_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        std::memcpy(st.host, host.data(), size_t(n) * sizeof(AugDev));
+        WW_HIP(hipMemcpyAsync(plan, st.host, size_t(n) * sizeof(AugDev), hipMemcpyHostToDevice, stream));
+        WW_HIP(hipEventRecord(st.ev, stream));
+        st.in_use = true;
+    }
+    return launch_augment_records(pcm, n, stride, plan, any_pitch != 0, any_stretch != 0, out, out_stride, workspace, stream);
 }
 
 }  // namespace ww

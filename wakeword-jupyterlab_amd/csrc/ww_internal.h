@@ -119,6 +119,10 @@ void set_logmel_math_mode(int mode);
 int launch_augment(const float* pcm, int64_t n, int64_t stride, const ww_augment_plan* plans_host, float* out,
                    int64_t out_stride, void* workspace, hipStream_t stream);
 int64_t augment_workspace_bytes(int64_t n);
+int augment_prepare(const ww_augment_plan* plans_host, int64_t n, void* records_host, int* any_pitch_out, int* any_stretch_out);
+int64_t augment_record_bytes();
+int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const void* records_dev, bool any_pitch, bool any_stretch, float* out,
+                           int64_t out_stride, void* workspace, hipStream_t stream);
 void build_kaiser_best(float* out /*[32769]*/);
 int sync_timeouts(unsigned int* count);   // bounded LDS-counter waits that expired (must be 0)
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
