@@ -115,17 +115,27 @@ __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, c
         const double phi = double(k) * two_pi * 0.25;            // hop * 2 pi k / n_fft
         const float2 d0 = Dc[k];
         float acc = atan2f(d0.y, d0.x);                          // np.angle(D[:, 0]): float32 accumulator
+        // |c| and angle(c) of the two columns a step reads are kept from the previous step: the column index moves on by 0, 1 or 2 per
+        // step (uniform over the workgroup), so most steps compute one new column instead of two (same values, a third less work)
+        int have = -2;                                           // columns `have`, `have + 1` are in (m0, a0), (m1, a1)
+        float m0 = 0.f, a0 = 0.f, m1 = 0.f, a1 = 0.f;
         for (int t = 0; t < n_out; ++t) {
             const double step = double(t) * rate;                // np.arange(0, n, rate)[t]
             const int i0 = int(step);
             const double alpha = step - double(i0);
-            const float2 c0 = pv_col(Dc, i0, k), c1 = pv_col(Dc, i0 + 1, k);
-            const float m0 = hypotf(c0.x, c0.y), m1 = hypotf(c1.x, c1.y);
+            if (i0 != have) {
+                if (i0 == have + 1) { m0 = m1; a0 = a1; }
+                else { const float2 c0 = pv_col(Dc, i0, k); m0 = hypotf(c0.x, c0.y); a0 = atan2f(c0.y, c0.x); }
+                const float2 c1 = pv_col(Dc, i0 + 1, k);
+                m1 = hypotf(c1.x, c1.y);
+                a1 = atan2f(c1.y, c1.x);
+                have = i0;
+            }
             const float mag = float(1.0 - alpha) * m0 + float(alpha) * m1;
             float sn, cs;
             sincosf(acc, &sn, &cs);
             Sc[int64_t(t) * kSpec + k] = make_float2(cs * mag, sn * mag);
-            const float da = atan2f(c1.y, c1.x) - atan2f(c0.y, c0.x);
+            const float da = a1 - a0;
             double dphase = double(da) - phi;
             dphase = dphase - two_pi * rint(dphase / two_pi);
             acc = float(double(acc) + (phi + dphase));
