@@ -153,7 +153,7 @@ int launch_conv2_wgrad_h(const float* mel, const uint32_t* maskbits, const float
                          float* partial, int grid, hipStream_t st);
 
 int launch_conv3_wgrad_h(const float* act2, const float* apow2, const uint32_t* maskbits, const float* gp, int64_t n, float* partial,
-                         float* reduced, int grid, hipStream_t st);
+                         float* dw, float* db, int grid, hipStream_t st);
 int64_t dgrad_h_scratch_floats(int64_t n, int n_conv);
 float* dgrad_h_scratch2(float* scratch, int64_t n);
 float* dgrad_h_dzs(float* scratch, int64_t n);

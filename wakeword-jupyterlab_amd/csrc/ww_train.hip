@@ -433,7 +433,8 @@ __global__ __launch_bounds__((DgradCfg<CIN, COUT>::kWaves * 64), 1) void conv_dg
 
 // out[i] = sum over workgroups g of partial[g][i] in a fixed order: 256 threads = 64 outputs x 4 slices of the groups (g = 4 q + slice),
 // the four slice sums added in order
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int groups, int len, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int groups, int len, int w_len,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
     __shared__ float part[4][64];
     const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
     for (int i0 = blockIdx.x * 64; i0 < len; i0 += gridDim.x * 64) {
@@ -443,7 +444,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
             for (int g = sl; g < groups; g += 4) s += partial[int64_t(g) * len + i];
         part[sl][c] = s;
         __syncthreads();
-        if (sl == 0 && i < len) out[i] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        if (sl == 0 && i < len) {                          // the weight part and the bias part go straight to their gradient tensors
+            const float v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+            if (i < w_len) dw[i] = v;
+            else db[i - w_len] = v;
+        }
         __syncthreads();
     }
 }
@@ -700,12 +705,11 @@ int train_forward(const float* mel, int64_t n, int width, const ww_train_params*
                                 w.gates1, w.mask1, w.hd1, p_lstm, p_fc, seed, logits, st);
 }
 
-// partial[groups][len] -> reduced, then the weight and the bias part go to their gradient tensors
+// partial[groups][len] -> the weight part and the bias part of the gradient
 static int reduce_to(const TrainWs& w, int groups, int len, int w_len, float* dw, float* db, int b_len, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 63) / 64 < 1024 ? (len + 63) / 64 : 1024), dim3(256), 0, st, w.partial, groups, len, w.reduced);
+    (void)b_len;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 63) / 64 < 1024 ? (len + 63) / 64 : 1024), dim3(256), 0, st, w.partial, groups, len, w_len, dw, db);
     WW_HIP(hipGetLastError());
-    WW_HIP(hipMemcpyAsync(dw, w.reduced, sizeof(float) * w_len, hipMemcpyDeviceToDevice, st));
-    WW_HIP(hipMemcpyAsync(db, w.reduced + w_len, sizeof(float) * b_len, hipMemcpyDeviceToDevice, st));
     return WW_OK;
 }
 
@@ -745,9 +749,7 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     if (nc == 3) {
         if (!bits) hipLaunchKernelGGL(pack_dgrad_b_dev_kernel, dim3(288), dim3(256), 0, st, p->conv_weight[2], 128, 64, w.dgrad3_b_op);
         if (bits) {
-            if (int rc = launch_conv3_wgrad_h(w.mid2, w.apow2, w.maskbits, w.gp, n, w.partial, w.reduced, grid, st)) return rc;
-            WW_HIP(hipMemcpyAsync(g->conv_weight[2], w.reduced, sizeof(float) * 128 * 64 * 9, hipMemcpyDeviceToDevice, st));
-            WW_HIP(hipMemcpyAsync(g->conv_bias[2], w.reduced + 128 * 64 * 9, sizeof(float) * 128, hipMemcpyDeviceToDevice, st));
+            if (int rc = launch_conv3_wgrad_h(w.mid2, w.apow2, w.maskbits, w.gp, n, w.partial, g->conv_weight[2], g->conv_bias[2], grid, st)) return rc;
         } else {
             hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, false, false>), dim3(grid), dim3(512), kWg3Lds, st,
                                mel, w.mid2, w.mid3, w.gp, N, width, w1, b1, w.partial);

@@ -687,7 +687,8 @@ __global__ __launch_bounds__(768, 3) void conv3_wgrad_h_kernel(const float* __re
 
 // sum of the workgroups' lane-order partials in a fixed order (four slices of the groups per output, added in order), un-permuted to
 // torch's [128][64][3][3] (+ bias).  Thread -> SOURCE index (coalesced reads); the destination follows from it.
-__global__ __launch_bounds__(256) void reduce_wgrad3_h_kernel(const float* __restrict__ partial, int groups, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void reduce_wgrad3_h_kernel(const float* __restrict__ partial, int groups, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
     constexpr int kW = 128 * 64 * 9, kP = kW + 128;
     __shared__ float part[4][64];
     const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -706,7 +707,9 @@ __global__ __launch_bounds__(256) void reduce_wgrad3_h_kernel(const float* __res
                 const int co = 64 * hf + 16 * (wave & 3) + 4 * (lane >> 4) + j, ci = 16 * (2 * (wave >> 2) + u) + (lane & 15);
                 dst = (co * 64 + ci) * 9 + t;
             }
-            out[dst] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+            const float v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+            if (src < kW) dw[dst] = v;
+            else db[src - kW] = v;
         }
         __syncthreads();
     }
@@ -1249,13 +1252,13 @@ int launch_conv2_wgrad_h_dense(const float* mel, const float* dz2h, const float*
     return WW_OK;
 }
 
-// conv3 weight gradient of the 3-conv model: partial [grid][128*64*9 + 128] (lane order) -> reduced [128*64*9 + 128] in torch order
+// conv3 weight gradient of the 3-conv model: partial [grid][128*64*9 + 128] (lane order) -> dw [128][64][3][3], db [128]
 int launch_conv3_wgrad_h(const float* act2, const float* apow2, const uint32_t* maskbits, const float* gp, int64_t n, float* partial,
-                         float* reduced, int grid, hipStream_t st) {
+                         float* dw, float* db, int grid, hipStream_t st) {
     if (int rc = train_h_opt_in()) return rc;
     hipLaunchKernelGGL(conv3_wgrad_h_kernel, dim3(grid), dim3(768), Wg3H::kLds, st, act2, apow2, reinterpret_cast<const uint8_t*>(maskbits), gp,
                        int(n), partial);
-    hipLaunchKernelGGL(reduce_wgrad3_h_kernel, dim3(1024), dim3(256), 0, st, partial, grid, reduced);
+    hipLaunchKernelGGL(reduce_wgrad3_h_kernel, dim3(1024), dim3(256), 0, st, partial, grid, dw, db);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
