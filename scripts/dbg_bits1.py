@@ -17,12 +17,12 @@ o = 0
 def take(f):
     global o
     at = o; o += a256(f); return at
-take(n * 80 * 64 * 32); take(n * 64)
+take(n * 64)                     # (relu(conv2) is not stored by the split-precision forward of the 2-conv model)
 for _ in range(2): take(4 * n * 256); take(n * 256); take(n * 256)
 take((64 + 256) * 768 + 2 * 768); take(2 * 144 * 64); take(2 * 144 * 64)
 take(n * 256); take(n * 1024); take(n * 256); take(n * 1024); take(n * 64); take(n * 64)
 kp = 64 * 32 * 9 + 64
-take(256 * kp); take(kp)
+take(256 * kp)
 mb = take(n * 80 * 32 * 2); take(int(nat.lib.ww_packed_weights_floats(2))); b1 = take(n * 80 * 32)
 bits1 = ws[b1:b1 + n * 80 * 32].reshape(n, 80, 32)
 # conv2's mask image = the accumulator ballots: [clip][40 tile rows][4 N-tiles][2 column halves][2 rows][4 j] x 64 bits,

@@ -569,7 +569,7 @@ constexpr int kMaxGroups = 256;                      // grids never exceed the C
 
 struct TrainWs {
     float *mid2, *mid3, *dz2, *pooled, *gates0, *mask0, *hd0, *gates1, *mask1, *hd1, *lstm_packed, *conv2_b_op, *conv3_b_op, *dgrad2_b_op, *dgrad3_b_op;
-    float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *partial, *reduced;
+    float *dhd1, *dg1, *dhd0, *dg0, *dpooled, *gp, *partial;
     uint32_t* maskbits;                                  // [n][80][32][c_last / 32]: [relu(last conv) > 0]
     float* wpk;                                          // split precision: packed image written on the device
     uint32_t* bits1;                                     // split precision: [n][80][32] sign bits of conv1
@@ -621,7 +621,6 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv, int mode = -1) {
     w.dhd1 = take(n * kHidden); w.dg1 = take(n * 4 * kHidden); w.dhd0 = take(n * kHidden); w.dg0 = take(n * 4 * kHidden);
     w.dpooled = take(n * c_last); w.gp = take(n * c_last);
     w.partial = take(int64_t(kMaxGroups) * (n_conv == 3 ? kWg3Partial : kWg2Partial));      // reused by every partial-producing kernel in turn
-    w.reduced = take(n_conv == 3 ? kWg3Partial : kWg2Partial);
     w.maskbits = reinterpret_cast<uint32_t*>(take(n * kTH * kTW * (c_last / 32)));
     w.wpk = take(packed_layout(n_conv).total);
     w.bits1 = reinterpret_cast<uint32_t*>(take(n * kTH * kTW));
