@@ -287,6 +287,10 @@ WW_API int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, 
 /* Diagnostic: the packed image (ww_packed_weights_floats(2) floats) that the last WW_TRAIN_MATH_F16X3 forward of the 2-conv model wrote on
  * the device from the live parameters -- its conv1 / conv2-Winograd / range entries equal ww_pack_weights_host's bit for bit; the rest is 0. */
 WW_API int ww_train_packed_image(const void* workspace_dev, int64_t n, int32_t n_conv, float* img_dev, ww_stream_t stream);
+/* Diagnostic: what the last WW_TRAIN_MATH_F16X3 forward on this workspace kept of the activations instead of the activations themselves --
+ * mask_last_dev [n][80][32][C/8] bytes, bit c of the position = [relu(last conv)[c] > 0] (C = 64 | 128, byte cb = channels 8 cb ..), in canonical
+ * order (the kernels' own image holds the accumulator ballots); sign1_dev [n][80][32] words, bit c = [relu(conv1)[c] > 0]. */
+WW_API int ww_train_bit_images(const void* workspace_dev, int64_t n, int32_t n_conv, uint8_t* mask_last_dev, uint32_t* sign1_dev, ww_stream_t stream);
 /* Arithmetic of the training step's convolution kernels, process-wide (the head is always exact fp32):
  *   WW_TRAIN_MATH_F32    exact fp32 matrix instructions throughout (v_mfma_f32_32x32x2_f32)
  *   WW_TRAIN_MATH_F16X3  (default) the conv stack in split precision on the f16 matrix instructions, for both models: forward = the

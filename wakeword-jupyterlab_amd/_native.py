@@ -116,6 +116,7 @@ PROTOTYPES = {
                                         C.c_void_p]),
     "ww_train_masks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_train_packed_image": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ww_train_bit_images": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_streamer_create": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "ww_streamer_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_streamer_window": (C.c_int, [C.c_void_p, C.c_void_p]),

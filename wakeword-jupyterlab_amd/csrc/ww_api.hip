@@ -371,6 +371,11 @@ int ww_train_packed_image(const void* workspace_dev, int64_t n, int32_t n_conv, 
     return train_packed_image(workspace_dev, n, n_conv, img_dev, static_cast<hipStream_t>(stream));
 }
 
+int ww_train_bit_images(const void* workspace_dev, int64_t n, int32_t n_conv, uint8_t* mask_last_dev, uint32_t* sign1_dev, ww_stream_t stream) {
+    if (!workspace_dev || !mask_last_dev || !sign1_dev || n < 1 || (n_conv != 2 && n_conv != 3)) return fail(WW_EINVAL, "ww_train_bit_images: bad arguments");
+    return train_bit_images(workspace_dev, n, n_conv, mask_last_dev, sign1_dev, static_cast<hipStream_t>(stream));
+}
+
 int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params, const float* dlogits_dev,
                           void* workspace_dev, const ww_train_grads* grads, ww_stream_t stream) {
     if (int rc = check_train(mel_dev, n, width, params, workspace_dev)) return rc;

@@ -140,6 +140,8 @@ int train_forward(const float* mel, int64_t n, int width, const ww_train_params*
                   float* logits, hipStream_t st);
 int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, float* mask1, hipStream_t st);
 int train_packed_image(const void* workspace, int64_t n, int n_conv, float* img, hipStream_t st);
+int train_bit_images(const void* workspace, int64_t n, int n_conv, uint8_t* mask_last, uint32_t* sign1, hipStream_t st);
+int launch_decode_mask_image(const uint32_t* img, int64_t n, int C, uint8_t* out, hipStream_t st);
 int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
                    const ww_train_grads* g, hipStream_t st);
 

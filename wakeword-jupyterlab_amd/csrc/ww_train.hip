@@ -667,6 +667,15 @@ int train_packed_image(const void* workspace, int64_t n, int n_conv, float* img,
     return WW_OK;
 }
 
+// test / diagnostic: the ReLU bit images the last split-precision forward left in the workspace, in canonical order
+int train_bit_images(const void* workspace, int64_t n, int n_conv, uint8_t* mask_last, uint32_t* sign1, hipStream_t st) {
+    if (workspace_mode(workspace) == WW_TRAIN_MATH_F32) return fail(WW_EINVAL, "this workspace's forward ran in exact fp32: no bit images");
+    TrainWs w = carve_train(const_cast<void*>(workspace), n, n_conv, workspace_mode(workspace));
+    if (int rc = launch_decode_mask_image(w.maskbits, n, n_conv == 3 ? 128 : 64, mask_last, st)) return rc;
+    WW_HIP(hipMemcpyAsync(sign1, w.bits1, sizeof(uint32_t) * n * kTH * kTW, hipMemcpyDeviceToDevice, st));
+    return WW_OK;
+}
+
 int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
                   float* logits, hipStream_t st) {
     if (device_cu_count() > kMaxGroups) return fail(WW_EUNSUPPORTED, "more than 256 CUs: the workspace is sized for 256 partials");

@@ -1209,6 +1209,23 @@ __global__ __launch_bounds__(512, 2) void conv3_dgrad_h_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// test / diagnostic: the last conv's mask image in canonical order, out[b][row][col][C/8 bytes], byte cb = channels 8 cb .. 8 cb + 7
+// ------------------------------------------------------------------------------------------------
+__global__ void decode_mask_image_kernel(const uint8_t* __restrict__ img, int64_t n, int C, uint8_t* __restrict__ out) {
+    const int64_t total = n * kTH * kTW * (C / 8);
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int cb = int(i % (C / 8)), col = int((i / (C / 8)) % kTW), row = int((i / (C / 8) / kTW) % kTH);
+        const int64_t clip = i / (int64_t(C / 8) * kTW * kTH);
+        out[i] = img[C == 64 ? mask2_byte(clip, row, col, cb) : mask3_byte(clip, row, col, cb)];
+    }
+}
+int launch_decode_mask_image(const uint32_t* img, int64_t n, int C, uint8_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(decode_mask_image_kernel, dim3(1024), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(img), n, C, out);
+    WW_HIP(hipGetLastError());
+    return WW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int train_h_opt_in() {

@@ -336,6 +336,16 @@ def train_last_packed_image() -> torch.Tensor:
     return img
 
 
+def train_last_bit_images():
+    """Diagnostic: (mask_last uint8 [n,80,32,C/8], sign1 int32 [n,80,32]) of the most recent split-precision training forward."""
+    ws, n, nc = _TrainStep.last_workspace, _TrainStep.last_n, _TrainStep.last_n_conv
+    mask = torch.empty((n, 80, 32, 8 if nc == 2 else 16), device=ws.device, dtype=torch.uint8)
+    sign1 = torch.empty((n, 80, 32), device=ws.device, dtype=torch.int32)
+    with torch.cuda.device(ws.device):
+        nat.check(nat.lib.ww_train_bit_images(_ptr(ws), n, nc, _ptr(mask), _ptr(sign1), _stream()))
+    return mask, sign1
+
+
 CONV_MATH = {"f32": 0, "f16x3": 1, "f16x3d": 2}
 
 
