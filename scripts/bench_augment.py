@@ -27,8 +27,9 @@ def measure(batch=4096, steps=10, check=8, device=0):
     x = pkg.synth.make_clips_tiled(0, B, unique=64)
     x = x / np.abs(x).max(axis=1, keepdims=True)
     pcm = torch.from_numpy(x).to(dev)
-    rng = random.Random(0)
-    plans = [ao.draw_plan(rng) for _ in range(B)]
+    random.seed(0)
+    proc = pkg.AudioProcessor()
+    plans = [proc.draw_augment_plan() for _ in range(B)]          # the product's own draws; the oracle below only CHECKS a few clips
     import ctypes as C
     from wakeword_jupyterlab_amd import _native as nat
     arr = (nat.AugmentPlan * B)()

@@ -70,7 +70,6 @@ def measure_pipeline(batch=4096, steps=4, device=0, arch="simple"):
     host, as the reference does) -> normalise + log-mel -> forward + CrossEntropyLoss + backward + Adam."""
     import random
     import wakeword_jupyterlab_amd as pkg
-    from oracle import augment_oracle as ao
     from wakeword_jupyterlab_amd import _native as nat
     from wakeword_jupyterlab_amd import ops
     dev = torch.device("cuda", device)
@@ -83,12 +82,13 @@ def measure_pipeline(batch=4096, steps=4, device=0, arch="simple"):
     x = pkg.synth.make_clips_tiled(0, batch, unique=64)
     pcm = torch.from_numpy(x / np.abs(x).max(axis=1, keepdims=True)).float().to(dev)
     y = torch.randint(0, 2, (batch,), device=dev)
-    rng = random.Random(0)
+    random.seed(0)
+    proc = pkg.AudioProcessor()
 
     def draw():
         arr = (nat.AugmentPlan * batch)()
         for a in arr:
-            p = ao.draw_plan(rng)
+            p = proc.draw_augment_plan()                          # the product's own draws (reference order, python `random`)
             a.shift, a.crop_start = p["shift"], p["crop"]
             a.pitch_rate = 2.0 ** (-p["n_steps"] / 12.0) if p["n_steps"] is not None else 0.0
             a.stretch_rate = p["rate"] or 0.0
