@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 3 /* 2: ww_set_logmel_math, ww_train_*, third conv-math mode; 3: ww_set_train_math (round 2) */
+#define WW_ABI_VERSION 4 /* 2: ww_set_logmel_math, ww_train_*, third conv-math mode; 3: ww_set_train_math (round 2); 4: ww_wav_reader_*, ww_read_wav_batch_host (round 3) */
 
 #if defined(WW_BUILD)
 #define WW_API __attribute__((visibility("default")))
@@ -43,6 +43,7 @@ extern "C" {
 #define WW_ENODEVICE (-2) /* no HIP device, or not gfx950 */
 #define WW_EHIP (-3)      /* a HIP runtime call failed */
 #define WW_EUNSUPPORTED (-4)
+#define WW_ENOSPACE (-5)  /* a caller-sized buffer (the WAV reader's staging) is too small for this request */
 
 /* AudioConfig, wakeword_training_script.py:29-37 (dup wakeword_training.ipynb cell 3);
  * Config, wakeword_training/train_wakeword.py:16-25; ModelConfig, wakeword_training_script.py:39-43 */
@@ -144,6 +145,44 @@ WW_API int ww_resampler_prepare(int32_t sample_rate, ww_clip_desc* desc_host);
 /* raw_dev: the files' sample bytes; descs_dev: [n_clips] descriptors in device memory; pcm_out_dev [n_clips][16000]. */
 WW_API int ww_decode_resample(const uint8_t* raw_dev, const ww_clip_desc* descs_dev, int64_t n_clips, int normalize,
                               float* pcm_out_dev, ww_stream_t stream);
+
+/* ---- file-fed batches: the host half of load_audio for many files at once ------------------------------------- */
+/* Replaces, for a batch of paths, the file access of AudioProcessor.load_audio = librosa.load(path, sr=16000)
+ * (wakeword_training_script.py:65-71) as it is driven by WakewordDataset.__getitem__ (:204-216) under
+ * DataLoader(batch_size=16, num_workers=2) (:461-463) -- the loop that bounds the reference at 453 clips/s
+ * (wakeword_training.ipynb:742).  A reader owns `n_threads` host threads, `n_slots` pinned staging buffers with their
+ * device twins, and a copy stream.  Per batch:
+ *   ww_read_wav_batch_host  the threads open the files, walk the RIFF chunks and pread the sample bytes straight into
+ *                           the slot's pinned staging; one ww_clip_desc per file is filled in (host, pinned; returned so
+ *                           that the caller can set crop_start -- pad_or_truncate's random crop (:78-83) stays the
+ *                           caller's draw: n_out = ceil(n_frames * up / down) is known now).  status_host[i] = 1, or a
+ *                           WW_WAV_E* code for a file that could not be used (the reference prints and substitutes
+ *                           zeros, :66-71, :210-211: such a file decodes to a zero clip here).  Blocks until the slot's
+ *                           previous upload has left the staging buffer.
+ *   ww_wav_batch_decode     H2D copy of the slot on the reader's copy stream, then K0 (ww_decode_resample) on `stream`
+ *                           behind it: pcm_out_dev [n][16000].  Asynchronous; the next ww_read_wav_batch_host on ANOTHER
+ *                           slot overlaps with it.  The upload of a slot waits for the K0 that last read its device twin. */
+#define WW_WAV_EOPEN (-1)    /* cannot open */
+#define WW_WAV_ENOTRIFF (-2) /* not a RIFF/WAVE file */
+#define WW_WAV_ECHUNK (-3)   /* fmt or data chunk missing / truncated */
+#define WW_WAV_EFORMAT (-4)  /* encoding K0 does not take (it takes PCM u8/s16/s24/s32 and float32), or an absurd rate */
+#define WW_WAV_EIO (-5)      /* read error */
+#define WW_WAV_ESPACE (-6)   /* the staging buffer was full (the call then returns WW_ENOSPACE with the size needed) */
+typedef struct ww_wav_reader ww_wav_reader;
+/* flags: WW_READER_HOST_ONLY = staging in ordinary host memory, no device twin, no GPU needed (ww_wav_batch_decode then returns
+ * WW_EUNSUPPORTED): the RIFF walk and the threaded reads can be checked -- and run under a sanitizer -- on a CPU-only machine. */
+#define WW_READER_HOST_ONLY 1
+WW_API int ww_wav_reader_create(int32_t n_threads, int32_t n_slots, int64_t max_clips, int64_t max_raw_bytes, int32_t flags, ww_wav_reader** out);
+WW_API int ww_wav_reader_destroy(ww_wav_reader* r);
+/* The slot's staging buffer as the last ww_read_wav_batch_host left it (descs[i].byte_offset points into it); for tests. */
+WW_API int ww_wav_reader_staging(ww_wav_reader* r, int32_t slot, const uint8_t** raw_host_out, int64_t* raw_bytes_out);
+/* One file's header only (no GPU needed): returns 1 and fills n_frames / channels / sample_rate / format / up / down / half_len, with
+ * byte_offset = the position of the sample data INSIDE THE FILE; or a WW_WAV_E* code. */
+WW_API int ww_wav_probe_host(const char* path, ww_clip_desc* desc_host);
+/* raw_bytes_out (may be NULL): sample bytes of the batch, 16-byte aligned per file; on WW_ENOSPACE the size to create a reader with. */
+WW_API int ww_read_wav_batch_host(ww_wav_reader* r, const char* const* paths, int64_t n, int32_t slot, ww_clip_desc** descs_host_out,
+                                  int8_t* status_host, int64_t* raw_bytes_out);
+WW_API int ww_wav_batch_decode(ww_wav_reader* r, int32_t slot, int normalize, float* pcm_out_dev, ww_stream_t stream);
 
 /* ---- KA: training-time augmentation ------------------------------ */
 /* Replaces AudioProcessor.augment_audio (wakeword_training_script.py:103-123): np.roll time shift ->

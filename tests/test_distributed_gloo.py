@@ -35,6 +35,18 @@ def _worker(rank, world, port, n_total, q):
     local = torch.stack([torch.arange(lo, hi, dtype=torch.float32), -torch.arange(lo, hi, dtype=torch.float32)], 1)
     full = wd.all_gather_logits(local, n_total)
     full_nohint = wd.all_gather_logits(local)              # without n_total: padded to the largest shard
+    # the bench step's exchange: double-buffered gathers, five steps, step k's logits = (rank, k)
+    pipe = wd.LogitsGatherPipeline(3, "cpu")
+    assert pipe.active and pipe.world == world and pipe.backend == "gloo"
+    seen = []
+    for k in range(5):
+        buf = pipe.acquire()
+        buf[:, 0], buf[:, 1] = float(rank), float(k)
+        seen.append(pipe.submit())
+    pipe.drain()
+    for k in (3, 4):                                       # the two live buffer pairs hold the last two steps
+        assert torch.equal(seen[k][:, 1], torch.full((world * 3,), float(k)))
+        assert torch.equal(seen[k][:, 0], torch.arange(world, dtype=torch.float32).repeat_interleave(3))
     q.put((rank, lo, hi, full.numpy(), full_nohint.shape[0]))
     dist.barrier()
     dist.destroy_process_group()
@@ -79,3 +91,30 @@ def test_single_process_is_a_no_op():
     assert init_from_env("gloo") == (0, 1, 0)
     x = torch.randn(5, 2)
     assert all_gather_logits(x) is x
+
+
+def _forced_single(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from wakeword_jupyterlab_amd import distributed as wd
+    assert wd.init_from_env("gloo", force=True) == (0, 1, 0) and dist.is_initialized()
+    x = torch.randn(5, 2)
+    y = wd.all_gather_logits(x, 5)                         # a 1-rank group still runs the collective
+    pipe = wd.LogitsGatherPipeline(4, "cpu")
+    pipe.acquire().fill_(7.0)
+    g = pipe.submit()
+    pipe.drain()
+    q.put((y is not x and torch.equal(x, y), bool((g == 7.0).all()) and g.shape == (4, 2) and pipe.active))
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_runs_the_collective():
+    """What tests/_rccl_child.py does with RCCL on the GPU box, rehearsed here on gloo: WORLD_SIZE=1 with a real group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_single, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) == (True, True)
+    p.join(timeout=60)
+    assert p.exitcode == 0

@@ -6,6 +6,7 @@
   * load_checkpoint of a {'model_state_dict': ...} file (wakeword_training_script.py:327-335) onto the device, checked
     against the reference-generated goldens
   * sharded_forward_pcm with two ranks (fresh processes, gloo rendezvous, both on the one GPU of the box)
+  * the RCCL gather path (one-rank `nccl` group in a fresh process): the async double-buffered all-gather of bench.py's step
   * streaming at BASELINE configs[4]'s size: 256 microphones, 10 ms hop
 """
 import os
@@ -183,6 +184,19 @@ def test_sharded_forward_pcm_two_ranks_on_one_gpu(tmp_path):
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{se[-3000:]}"
         assert "SHARDED_OK" in so, so[-2000:]
+
+
+def test_rccl_gather_path_one_rank():
+    """The RCCL path itself (`backend="nccl"`), executed: a fresh process with a one-rank RCCL group on this box's GPU runs the
+    double-buffered async all-gather of bench.py's step (distributed.LogitsGatherPipeline) for seven steps, `sharded_forward_pcm`
+    and `all_gather_logits`; gathered logits must equal the local ones bit for bit.  The 8-GPU run is then not the first time
+    this code meets RCCL."""
+    port = 31500 + os.getpid() % 2000
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_child.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "RCCL_OK" in p.stdout, p.stdout[-2000:]
 
 
 # ---------------------------------------------------------------------------------------------------------------

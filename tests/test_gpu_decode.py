@@ -109,3 +109,38 @@ def test_dataset_batches_with_gpu_decode_feed_the_model(tmp_path):
     # per-item access (reference signature) agrees with the batched path
     item, label = ds[1]
     assert item.shape == (1, 80, 32) and label.tolist() == [1] and np.abs(item.numpy() - mel[1]).max() <= 1e-4
+
+
+def test_reader_slots_overlap_without_corrupting_batches(tmp_path):
+    """The file-fed pipeline's buffer rotation: eight batches of different files go through a 2-slot reader back to back with no
+    synchronisation in between (host threads fill slot s+1 while the upload / K0 of slot s are in flight; a slot's next upload
+    waits for the K0 that read its device twin, its next read for the upload that left its staging).  Every batch must come
+    out as the oracle decodes it -- a protocol slip shows up as another batch's samples."""
+    from wakeword_jupyterlab_amd.files import WavBatchReader
+    dev = torch.device("cuda", 0)
+    n_batches, per = 8, 48
+    paths, refs = [], []
+    for i in range(n_batches * per):
+        x = pkg.synth.make_clip(1000 + i)[: 16000 - 37 * (i % 11)] * (0.3 + 0.01 * (i % 50))
+        p = os.path.join(tmp_path, f"p{i:04d}.wav")
+        _write_wav(p, x, 16000)
+        paths.append(p)
+        refs.append(decode_oracle.load_normalise_crop(*_read_wav(p)))
+    rd = WavBatchReader(max_clips=per, max_raw_bytes=per * 32016, threads=4, slots=2, device=dev)
+    outs = [torch.empty((per, 16000), device=dev) for _ in range(n_batches)]
+    for b in range(n_batches):
+        _, ok = rd.load(paths[b * per:(b + 1) * per], normalize=True, out=outs[b])
+        assert ok.all()
+    torch.cuda.synchronize()
+    got = torch.cat(outs).cpu().numpy()
+    assert np.abs(got - np.stack(refs)).max() <= 2e-7
+    # a batch that does not fit: load() re-creates the reader with the size the library asked for
+    long = os.path.join(tmp_path, "long.wav")
+    _write_wav(long, _tone(16000 * 120, 16000, 3) * 0.5, 16000)                 # 3.8 MB > the 1.5 MB staging
+    random.seed(3)
+    out, ok = rd.load([long, paths[0]], normalize=True)
+    random.seed(3)
+    start = random.randint(0, 16000 * 119)
+    assert ok.all() and np.abs(out[0].cpu().numpy() - decode_oracle.load_normalise_crop(*_read_wav(long), start)).max() <= 2e-7
+    assert np.abs(out[1].cpu().numpy() - refs[0]).max() <= 2e-7
+    rd.close()

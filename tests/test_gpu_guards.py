@@ -8,6 +8,14 @@ power-of-two exponents per output channel (weights), per clip (inputs, activatio
 Oracle: oracle/model_oracle.forward_np (float64 arithmetic on the float32 parameters).  Tolerance: 1e-3 on logits
 (north_star); the worst error of every case is written to gpurun_out/guard_errors.json when that directory exists.
 
+The logits alone cannot see the conv arithmetic in most of these cases (saturated gates: a 1e-3 relative change of the
+pooled features moves the logits by < 1e-4 in 12 of the 14 weight cases), so every case ALSO compares the conv stack's
+output itself: `ops.cnn_pool` against `model_oracle.pooled_features_np`, per clip relative to the clip's largest pooled
+feature, under the arithmetic being tested AND under the exact-fp32 kernels on the same inputs.  Required:
+    err(split) <= 2 * err(f32 kernels) + 2^-22      and      err(split) <= 1e-5
+-- a single f16 MFMA per product block (2^-11) misses both by three orders of magnitude.  The head has its own twin on
+rows whose gates are NOT saturated, with a self-check that the case would fail under plain-f16 inputs.
+
 Also: an expired in-kernel wait poisons the workgroup's outputs with NaN (observed through the diagnostic twin
 library whose waits expire at once), and single clips of any length go through the C ABI.
 """
@@ -27,8 +35,12 @@ from oracle import mel_oracle, model_oracle
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-3
+POOLED_REL_CAP = 1e-5            # |pooled - float64 oracle| / max|pooled of the clip|, any arithmetic
+SPLIT_EPS = 2.0 ** -22           # what the dropped lo*lo term of the split may add on top of the fp32 kernels' own error
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _WORST = {}
+_WORST_POOLED = {}
+_WORST_HEAD = {}
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +55,11 @@ def _report():
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out) and _WORST:
         with open(os.path.join(out, "guard_errors.json"), "w") as f:
-            json.dump({"tolerance": LOGIT_TOL, "worst_logit_abs_err": _WORST, "max": max(_WORST.values())}, f, indent=1, sort_keys=True)
+            json.dump({"tolerance": LOGIT_TOL, "worst_logit_abs_err": _WORST, "max": max(_WORST.values()),
+                       "pooled_rel_cap": POOLED_REL_CAP, "split_eps": SPLIT_EPS,
+                       "worst_pooled_rel_err": _WORST_POOLED,      # {case: {"err": this arithmetic, "err_f32_kernels": ...}}
+                       "max_pooled_rel_err": max([v["err"] for v in _WORST_POOLED.values()] or [0.0]),
+                       "head_unsaturated": _WORST_HEAD}, f, indent=1, sort_keys=True)
 
 
 @pytest.fixture(params=["f16x3", "f16x3d", "f32"])
@@ -125,7 +141,21 @@ def _run(arch, sd, x, dev):
         return m(torch.from_numpy(x).to(dev)).cpu().numpy()
 
 
+def _pooled_rel_err(arch, sd, x, dev, ref):
+    """max over clips of max_c |cnn_pool - ref| / max_c |ref| (the clip's largest pooled feature), current conv math."""
+    from wakeword_jupyterlab_amd import ops
+    n_conv = 2 if arch == "simple" else 3
+    packed = torch.from_numpy(ops.pack_state_dict(sd)).to(dev)
+    got = ops.cnn_pool(torch.from_numpy(x).to(dev), packed, n_conv).cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all(), "non-finite pooled features where the reference is finite"
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    dead = scale[:, 0] == 0.0
+    assert (got[dead] == 0.0).all(), "a clip whose pooled features are all exactly 0 in float64 must come out 0"
+    return float((np.abs(got - ref)[~dead] / scale[~dead]).max()) if (~dead).any() else 0.0
+
+
 def _check(tag, arch, sd, x, dev, conv_math):
+    from wakeword_jupyterlab_amd import ops
     ref = model_oracle.forward_np(x, sd)
     assert np.isfinite(ref).all(), "the float64 oracle itself is not finite: bad test case"
     y = _run(arch, sd, x, dev)
@@ -133,6 +163,20 @@ def _check(tag, arch, sd, x, dev, conv_math):
     err = float(np.abs(y - ref).max())
     _WORST[f"{arch}/{conv_math}/{tag}"] = err
     assert err <= LOGIT_TOL, f"{tag}: logits max |err| = {err:.3e}"
+    # the conv stack itself, where the logits cannot hide it
+    pref = model_oracle.pooled_features_np(x, sd)
+    perr = _pooled_rel_err(arch, sd, x, dev, pref)
+    if conv_math == "f32":
+        perr32 = perr
+    else:
+        ops.set_conv_math("f32")
+        try:
+            perr32 = _pooled_rel_err(arch, sd, x, dev, pref)
+        finally:
+            ops.set_conv_math(conv_math)
+    _WORST_POOLED[f"{arch}/{conv_math}/{tag}"] = {"err": perr, "err_f32_kernels": perr32}
+    assert perr <= POOLED_REL_CAP, f"{tag}: pooled features off by {perr:.3e} of the clip's largest (cap {POOLED_REL_CAP:.0e})"
+    assert perr <= 2 * perr32 + SPLIT_EPS, f"{tag}: pooled rel. err {perr:.3e} under {conv_math} vs {perr32:.3e} under the exact-fp32 kernels"
 
 
 @pytest.mark.parametrize("arch", ["simple", "full"])
@@ -174,6 +218,44 @@ def test_head_rows_beyond_f16_range(dev, conv_math):
     err = float(np.abs(y - ref).max())
     _WORST[f"simple/{conv_math}/head_rows_1e-6..1e7"] = err
     assert np.isfinite(y).all() and err <= LOGIT_TOL
+
+
+def _f16_round(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["default", "lognormal", "outlier_x1000", "tiny_channels"])
+def test_head_on_unsaturated_rows(dev, conv_math, case):
+    """The LSTM gate GEMMs where the gates are NOT pinned at +-1: pooled rows scaled so that layer 0's largest |pre-activation|
+    is ~1.5.  The logits then carry the GEMM's error (self-check: the same rows rounded to plain f16 -- one MFMA per block --
+    move the float64 logits by >= 10x the bound asserted here)."""
+    from wakeword_jupyterlab_amd import ops
+    sd = _sd("simple") if case == "default" else _weights_case("simple", case)
+    r = _rng(11)
+    pooled = np.abs(r.standard_normal((64, 64))).astype(np.float64) + 0.05
+    w0 = sd["lstm.weight_ih_l0"].astype(np.float64)
+    b0 = sd["lstm.bias_ih_l0"].astype(np.float64) + sd["lstm.bias_hh_l0"].astype(np.float64)
+    g = pooled @ w0.T
+    pooled = (pooled * (1.5 / np.abs(g).max(axis=1, keepdims=True))).astype(np.float32)
+    assert np.abs(pooled.astype(np.float64) @ w0.T + b0).max() < 4.0
+    ref = model_oracle.head_np(pooled, sd)
+    teeth = float(np.abs(model_oracle.head_np(_f16_round(pooled), sd) - ref).max())     # what plain-f16 inputs alone would cost
+    packed = torch.from_numpy(ops.pack_state_dict(sd)).to(dev)
+    y = ops.lstm_fc(torch.from_numpy(pooled).to(dev), packed, 2).cpu().numpy()
+    err = float(np.abs(y - ref).max())
+    if conv_math == "f32":
+        err32 = err
+    else:
+        ops.set_conv_math("f32")
+        try:
+            err32 = float(np.abs(ops.lstm_fc(torch.from_numpy(pooled).to(dev), packed, 2).cpu().numpy() - ref).max())
+        finally:
+            ops.set_conv_math(conv_math)
+    scale = float(np.abs(ref).max())
+    bound = 2 * err32 + 1e-7
+    _WORST_HEAD[f"{conv_math}/{case}"] = {"err": err, "err_f32_kernel": err32, "plain_f16_inputs_would_cost": teeth, "logit_scale": scale}
+    assert np.isfinite(y).all() and err <= bound, f"{case}: head logits off by {err:.3e} (fp32 kernel {err32:.3e})"
+    assert teeth >= 10 * bound, f"{case}: this case cannot see the arithmetic (plain f16 would cost {teeth:.3e}, bound {bound:.3e})"
 
 
 def test_nan_and_inf_inputs_propagate_like_the_reference(dev, conv_math):

@@ -1,0 +1,160 @@
+"""CPU tests of the native batch WAV reader (csrc/ww_files.cpp) in its host-only mode: RIFF walk, threaded reads into the
+staging buffer, status codes, capacity handling.  The same code path feeds pinned staging on the GPU box
+(tests/test_gpu_decode.py drives it through K0 against oracle/decode_oracle.py).
+
+Reference behaviour being replaced: AudioProcessor.load_audio, /root/reference/wakeword_training_script.py:65-71 (one file at a
+time, print + None on failure); the expected header fields come from audio._parse_wav, the package's own host parser.
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import wakeword_jupyterlab_amd as pkg
+from wakeword_jupyterlab_amd import _native as nat
+from wakeword_jupyterlab_amd import files
+from wakeword_jupyterlab_amd.audio import _parse_wav
+
+
+def _chunk(cid, body):
+    return cid + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+
+
+def _wav(raw, sr=16000, bits=16, channels=1, tag=1, extra_before=b"", extra_after=b"", extensible=False, data_size=None):
+    fmt = struct.pack("<HHIIHH", 0xFFFE if extensible else tag, channels, sr, sr * channels * bits // 8, channels * bits // 8, bits)
+    if extensible:
+        fmt += struct.pack("<HHI", 22, bits, 0) + struct.pack("<H", tag) + b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+    data = b"data" + struct.pack("<I", len(raw) if data_size is None else data_size) + raw + (b"\0" if len(raw) & 1 else b"")
+    body = b"WAVE" + _chunk(b"fmt ", fmt) + extra_before + data + extra_after
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+@pytest.fixture()
+def corpus(tmp_path):
+    r = np.random.default_rng(7)
+    def s16(n, ch=1): return r.integers(-30000, 30000, n * ch).astype("<i2").tobytes()
+    cases = {
+        "plain16.wav": _wav(s16(16000)),
+        "short.wav": _wav(s16(777)),
+        "stereo44k.wav": _wav(s16(5000, 2), sr=44100, channels=2),
+        "list_before.wav": _wav(s16(4000), extra_before=_chunk(b"LIST", b"INFOISFT" + b"x" * 5001)),      # data chunk beyond the 4 KiB window
+        "fact_after.wav": _wav(s16(1234), extra_after=_chunk(b"fact", b"\x01\x02\x03")),
+        "u8.wav": _wav(r.integers(0, 255, 3001).astype(np.uint8).tobytes(), bits=8),
+        "s24.wav": _wav(r.integers(0, 255, 3 * 2000).astype(np.uint8).tobytes(), bits=24, sr=48000),
+        "s32.wav": _wav(r.integers(-2 ** 31, 2 ** 31 - 1, 900).astype("<i4").tobytes(), bits=32, sr=22050),
+        "f32.wav": _wav(r.standard_normal(1500).astype("<f4").tobytes(), bits=32, tag=3, sr=8000),
+        "ext.wav": _wav(s16(3000), extensible=True),
+        "cut.wav": _wav(s16(2000), data_size=100000),                         # header promises more than the file holds
+        "empty.wav": _wav(b""),
+        # unusable
+        "f64.wav": _wav(r.standard_normal(10).astype("<f8").tobytes(), bits=64, tag=3),
+        "notwav.wav": b"this is not a wave file at all",
+        "nodata.wav": b"RIFF" + struct.pack("<I", 4 + 24) + b"WAVE" + _chunk(b"fmt ", struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)),
+        "tiny.wav": b"RIFF",
+    }
+    paths = []
+    for name, blob in cases.items():
+        p = os.path.join(tmp_path, name)
+        with open(p, "wb") as f:
+            f.write(blob)
+        paths.append(p)
+    paths.append(os.path.join(tmp_path, "missing.wav"))
+    return paths, cases
+
+
+FMT_OF = {(1, 16): nat.FMT_S16, (1, 24): nat.FMT_S24, (1, 32): nat.FMT_S32, (3, 32): nat.FMT_F32, (1, 8): nat.FMT_U8}
+EXPECT_BAD = {"f64.wav": -4, "notwav.wav": -2, "nodata.wav": -3, "tiny.wav": -2, "missing.wav": -1}
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_reader_stages_every_file_like_the_python_parser(corpus, threads):
+    paths, cases = corpus
+    rd = files.WavBatchReader(max_clips=64, max_raw_bytes=1 << 20, threads=threads, slots=2, host_only=True)
+    for slot in (0, 1, 0):                                                     # slots are reusable
+        descs, status = rd.read(paths, slot)
+        stage = rd.staging(slot)
+        spans = []
+        for p, d, st in zip(paths, descs, status):
+            name = os.path.basename(p)
+            if name in EXPECT_BAD:
+                assert st == EXPECT_BAD[name], (name, st)
+                assert d["n_frames"] == 0 and d["up"] == 1 and d["down"] == 1     # K0 sees an empty clip -> a zero row
+                continue
+            assert st == 1, (name, st)
+            blob = cases[name]
+            tag, ch, sr, bits, start, length = _parse_wav(blob)
+            fb = ch * bits // 8
+            assert (d["channels"], d["sample_rate"], d["format"], d["n_frames"]) == (ch, sr, FMT_OF[(tag, bits)], length // fb), name
+            nbytes = int(d["n_frames"]) * fb
+            off = int(d["byte_offset"])
+            assert off % 16 == 0 and bytes(stage[off:off + nbytes]) == blob[start:start + nbytes], name
+            assert not stage[off + nbytes:(off + nbytes + 15) // 16 * 16].any()      # the alignment pad is zeroed
+            spans.append((off, (nbytes + 15) // 16 * 16))
+            from math import gcd
+            g = gcd(sr, 16000)
+            assert (d["up"], d["down"]) == (16000 // g, sr // g) and d["crop_start"] == 0
+        spans.sort()
+        assert all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:]))            # the bump allocator never overlaps files
+        assert sum(s[1] for s in spans) == len(stage)
+    with pytest.raises(RuntimeError):
+        rd.decode(0)                                                             # host-only: nothing to decode on
+    rd.close()
+
+
+def test_reader_reports_the_size_it_needs_and_load_regrows(corpus):
+    paths, _ = corpus
+    rd = files.WavBatchReader(max_clips=64, max_raw_bytes=4096, threads=3, host_only=True)
+    with pytest.raises(nat.NativeError) as e:
+        rd.read(paths, 0)
+    assert e.value.code == nat.WW_ENOSPACE and e.value.needed > 4096
+    need = e.value.needed
+    rd._regrow(64, need)
+    descs, status = rd.read(paths, 0)
+    assert (status == 1).sum() == len(paths) - len(EXPECT_BAD) and len(rd.staging(0)) == need
+    with pytest.raises(nat.NativeError):
+        rd.read(paths * 5, 0)                                                    # more files than the reader was created for
+    assert rd.read([], 1)[0].size == 0
+    rd.close()
+
+
+def test_many_files_many_threads_are_all_accounted_for(tmp_path):
+    """512 files of different lengths through 8 threads, three rounds: every payload arrives once, bit for bit."""
+    r = np.random.default_rng(1)
+    paths, payloads = [], []
+    for i in range(512):
+        raw = r.integers(-2 ** 15, 2 ** 15 - 1, 50 + 13 * (i % 97)).astype("<i2").tobytes()
+        p = os.path.join(tmp_path, f"c{i:03d}.wav")
+        with open(p, "wb") as f:
+            f.write(_wav(raw))
+        paths.append(p); payloads.append(raw)
+    rd = files.WavBatchReader(max_clips=512, max_raw_bytes=2 << 20, threads=8, slots=3, host_only=True)
+    for rnd in range(3):
+        descs, status = rd.read(paths, rnd)
+        stage = rd.staging(rnd)
+        assert (status == 1).all()
+        for d, raw in zip(descs, payloads):
+            assert bytes(stage[int(d["byte_offset"]):int(d["byte_offset"]) + len(raw)]) == raw
+    rd.close()
+
+
+def test_probe_reads_one_header(corpus):
+    paths, cases = corpus
+    for p in paths:
+        name = os.path.basename(p)
+        info = files.probe(p)
+        if name in EXPECT_BAD:
+            assert info is None
+        else:
+            tag, ch, sr, bits, start, length = _parse_wav(cases[name])
+            assert info["data_offset"] == start and info["n_frames"] == length // (ch * bits // 8) and info["sample_rate"] == sr
+
+
+def test_crop_draw_uses_python_random_like_pad_or_truncate():
+    import random
+    descs = np.zeros(3, dtype=files.DESC_DTYPE)
+    descs["n_frames"], descs["up"], descs["down"] = [16000, 48000 * 2, 30000], [1, 1, 1], [1, 3, 1]     # 1 s, 2 s at 48 kHz, 1.875 s
+    status = np.array([1, 1, -1], dtype=np.int8)
+    random.seed(5); want = random.randint(0, 32000 - 16000); random.seed(5)
+    files.WavBatchReader.draw_crops(descs, status)
+    assert list(descs["crop_start"]) == [0, want, 0]

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol_and_binding_covers_them():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert sorted(nat.PROTOTYPES) == names                 # ctypes table == header, nothing more, nothing less
-    assert nat.lib.ww_abi_version() == 3
+    assert nat.lib.ww_abi_version() == nat.ABI_VERSION == 4
     # nothing else leaks out of the shared object
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", nat.LIB_PATH], capture_output=True, text=True).stdout

@@ -18,8 +18,8 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WW_LIB_OVERRIDE") or os.path.join(_HERE, "libwakeword_amd.so")   # override: ablation builds only
 
-WW_OK, WW_EINVAL, WW_ENODEVICE, WW_EHIP, WW_EUNSUPPORTED = 0, -1, -2, -3, -4
-ABI_VERSION = 3
+WW_OK, WW_EINVAL, WW_ENODEVICE, WW_EHIP, WW_EUNSUPPORTED, WW_ENOSPACE = 0, -1, -2, -3, -4, -5
+ABI_VERSION = 4
 
 
 class NativeError(RuntimeError):
@@ -75,6 +75,8 @@ class AugmentPlan(C.Structure):
 
 
 FMT_S16, FMT_S24, FMT_S32, FMT_F32, FMT_U8 = 1, 2, 3, 4, 5
+WAV_STATUS = {1: "ok", -1: "cannot open", -2: "not a RIFF/WAVE file", -3: "missing fmt/data chunk", -4: "unsupported WAV encoding",
+              -5: "read error", -6: "staging buffer full"}
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header
 PROTOTYPES = {
@@ -94,6 +96,13 @@ PROTOTYPES = {
     "ww_resample_taps_host": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ww_resampler_prepare": (C.c_int, [C.c_int32, C.POINTER(ClipDesc)]),
     "ww_decode_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "ww_wav_reader_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ww_wav_reader_staging": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "ww_wav_probe_host": (C.c_int, [C.c_char_p, C.POINTER(ClipDesc)]),
+    "ww_wav_reader_destroy": (C.c_int, [C.c_void_p]),
+    "ww_read_wav_batch_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int64, C.c_int32, C.POINTER(C.POINTER(ClipDesc)), C.c_void_p,
+                                         C.POINTER(C.c_int64)]),
+    "ww_wav_batch_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p]),
     "ww_augment_workspace_bytes": (C.c_int64, [C.c_int64]),
     "ww_augment_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(AugmentPlan), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_augment_record_bytes": (C.c_int64, []),

@@ -195,50 +195,15 @@ class AudioProcessor:
         return ops.logmel(t, normalize)
 
     def load_clips_gpu(self, paths, normalize: bool = True):
-        """Host: read the files and parse their RIFF headers.  GPU (kernel K0): sample conversion, mono mix, polyphase
+        """Host: the library's reader threads open the files, walk their RIFF headers and read the sample bytes into pinned
+        staging (files.WavBatchReader -> ww_read_wav_batch_host).  GPU (kernel K0): sample conversion, mono mix, polyphase
         resample to 16 kHz, whole-file peak normalisation, random crop / zero pad to 1 s -- process_audio_file :125-133
         up to the mel call.  Returns (device tensor [B, 16000], ok mask); unreadable files give a zero row, ok False."""
-        import ctypes as C
-        from . import _native as nat
+        from .files import WavBatchReader
         dev = self._dev()
-        n = int(self.config.SAMPLE_RATE * self.config.DURATION)
-        fmt_of = {(1, 16): nat.FMT_S16, (1, 24): nat.FMT_S24, (1, 32): nat.FMT_S32, (3, 32): nat.FMT_F32, (1, 8): nat.FMT_U8}
-        descs = (nat.ClipDesc * len(paths))()
-        chunks, ok, offset, prepared = [], np.zeros(len(paths), dtype=bool), 0, {}
-        for i, path in enumerate(paths):
-            try:
-                with open(path, "rb") as f:
-                    data = f.read()
-                tag, ch, sr, bits, start, length = _parse_wav(data)
-                if (tag, bits) not in fmt_of or ch < 1:
-                    raise ValueError(f"unsupported WAV encoding tag={tag} bits={bits}")
-                frame_bytes = ch * bits // 8
-                frames = length // frame_bytes
-                if sr not in prepared:
-                    proto = nat.ClipDesc()
-                    with torch.cuda.device(dev):
-                        nat.check(nat.lib.ww_resampler_prepare(sr, C.byref(proto)))
-                    prepared[sr] = proto
-                d, proto = descs[i], prepared[sr]
-                d.byte_offset, d.n_frames, d.channels, d.sample_rate, d.format = offset, frames, ch, sr, fmt_of[(tag, bits)]
-                d.up, d.down, d.half_len, d.taps_dev = proto.up, proto.down, proto.half_len, proto.taps_dev
-                n_out = -(-frames * proto.up // proto.down)
-                d.crop_start = random.randint(0, n_out - n) if n_out > n else 0      # pad_or_truncate's random crop (:79-81)
-                body = data[start:start + frames * frame_bytes]
-                body += b"\0" * (-len(body) % 16)                                    # keep every file 16-byte aligned
-                chunks.append(body)
-                offset += len(body)
-                ok[i] = True
-            except Exception as e:                                                   # reference: print and carry on (:66-71)
-                print(f"Error loading {path}: {e}")
-                descs[i].n_frames, descs[i].channels, descs[i].format, descs[i].up, descs[i].down = 0, 1, nat.FMT_S16, 1, 1
-        raw = torch.frombuffer(bytearray(b"".join(chunks) or b"\0" * 16), dtype=torch.uint8).to(dev)
-        desc_t = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev) if len(paths) else torch.zeros(1, dtype=torch.uint8, device=dev)
-        out = torch.empty((len(paths), n), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
-            nat.check(nat.lib.ww_decode_resample(C.c_void_p(raw.data_ptr()), C.c_void_p(desc_t.data_ptr()), len(paths), int(bool(normalize)),
-                                                 C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        return out, ok
+        if getattr(self, "_reader", None) is None or self._reader.device != dev:
+            self._reader = WavBatchReader(max_clips=max(64, len(paths)), device=dev)
+        return self._reader.load(list(paths), normalize)
 
     def load_clips(self, paths, target_length=None):
         """Decode, peak-normalise and crop/pad a list of files on the host, in the reference's order

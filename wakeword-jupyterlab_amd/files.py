@@ -1,0 +1,163 @@
+"""File-fed batches: many WAV files -> normalised 1 s clips [B, 16000] on the GPU.
+
+Host half of the reference's `AudioProcessor.load_audio` (/root/reference/wakeword_training_script.py:65-71) as its
+`DataLoader(batch_size=16, num_workers=2)` drives it (:461-463), for a whole batch of paths at once: the library's thread
+pool opens the files, walks the RIFF chunks and reads the sample bytes straight into pinned staging
+(`ww_read_wav_batch_host`, csrc/ww_files.cpp); the slot goes to the GPU on the reader's copy stream and kernel K0 decodes,
+mixes to mono, resamples, peak-normalises and crops / zero-pads (`ww_wav_batch_decode`).  With two or more slots the host
+reads batch k+1 while the GPU works on batch k.  Python only hands over the path list and draws `pad_or_truncate`'s
+random crop (:78-83) with `random.randint`, like the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .config import CLIP_SAMPLES
+
+# struct ww_clip_desc as a numpy record (include/wakeword_amd.h): lets the crop draw and the status scan run vectorised
+DESC_DTYPE = np.dtype([("byte_offset", "<i8"), ("n_frames", "<i8"), ("channels", "<i4"), ("sample_rate", "<i4"), ("format", "<i4"),
+                       ("crop_start", "<i4"), ("up", "<i4"), ("down", "<i4"), ("half_len", "<i4"), ("_pad", "<i4"), ("taps_dev", "<u8")])
+assert DESC_DTYPE.itemsize == C.sizeof(nat.ClipDesc)
+
+
+def default_threads() -> int:
+    """Host threads of a reader: the box's CPU share for one GPU is 16; never more than the machine has."""
+    return max(1, min(16, os.cpu_count() or 1))
+
+
+class WavBatchReader:
+    """`read(paths, slot)` (host, blocking) -> `decode(slot)` (GPU, asynchronous) -> device tensor [B, 16000].
+
+    max_raw_bytes: sample bytes one batch may hold (16-byte aligned per file); grows on demand in `load()`."""
+
+    def __init__(self, max_clips: int = 4096, max_raw_bytes: int | None = None, threads: int | None = None, slots: int = 2, device=None,
+                 host_only: bool = False):
+        """host_only=True: staging in ordinary memory and no device twin -- `read()` works without a GPU (tests of the reader
+        threads and the RIFF walk), `decode()` raises."""
+        self.host_only = bool(host_only)
+        if not host_only and not torch.cuda.is_available():
+            raise RuntimeError("WavBatchReader feeds the GPU decode kernel (K0) and no GPU is visible (no CPU fallback)")
+        self.device = None if host_only else (torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        self.max_clips = int(max_clips)
+        self.max_raw_bytes = int(max_raw_bytes if max_raw_bytes is not None else max(1 << 20, self.max_clips * 2 * CLIP_SAMPLES + 4096))
+        self.threads = int(threads or default_threads())
+        self.slots = int(slots)
+        self._h = C.c_void_p()
+        with self._ctx():
+            nat.check(nat.lib.ww_wav_reader_create(self.threads, self.slots, self.max_clips, self.max_raw_bytes, int(self.host_only), C.byref(self._h)))
+        self._n = [0] * self.slots
+        self._next = 0
+
+    def _ctx(self):
+        import contextlib
+        return contextlib.nullcontext() if self.host_only else torch.cuda.device(self.device)
+
+    def staging(self, slot: int = 0) -> np.ndarray:
+        """The slot's staging bytes as the last `read` left them (a copy) -- descs['byte_offset'] index into it."""
+        p, n = C.c_void_p(), C.c_int64(0)
+        nat.check(nat.lib.ww_wav_reader_staging(self._h, slot, C.byref(p), C.byref(n)))
+        return np.frombuffer((C.c_char * max(1, n.value)).from_address(p.value), dtype=np.uint8, count=n.value).copy()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            nat.lib.ww_wav_reader_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def next_slot(self) -> int:
+        s = self._next
+        self._next = (s + 1) % self.slots
+        return s
+
+    def read(self, paths, slot: int = 0):
+        """Host threads read `paths` into the slot's pinned staging.  Returns (descs, status): a numpy record view of the
+        slot's descriptors (writable: set descs['crop_start'] before `decode`) and int8 status per file (1 = ok, else
+        _native.WAV_STATUS).  Raises NativeError(WW_ENOSPACE) with `.needed` set when the batch does not fit."""
+        n = len(paths)
+        arr = (C.c_char_p * max(1, n))(*[os.fsencode(p) for p in paths])
+        status = np.zeros(max(1, n), dtype=np.int8)
+        descs_p = C.POINTER(nat.ClipDesc)()
+        need = C.c_int64(0)
+        with self._ctx():
+            rc = nat.lib.ww_read_wav_batch_host(self._h, arr, n, slot, C.byref(descs_p), status.ctypes.data, C.byref(need))
+        if rc == nat.WW_ENOSPACE:
+            e = nat.NativeError(rc, (nat.lib.ww_last_error() or b"").decode("utf-8", "replace"))
+            e.needed = int(need.value)
+            raise e
+        nat.check(rc)
+        self._n[slot] = n
+        if n == 0:
+            return np.zeros(0, dtype=DESC_DTYPE), status[:0]
+        buf = (C.c_char * (n * DESC_DTYPE.itemsize)).from_address(C.addressof(descs_p.contents))
+        return np.frombuffer(buf, dtype=DESC_DTYPE, count=n), status[:n]
+
+    def decode(self, slot: int = 0, normalize: bool = True, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Upload the slot and run K0 on torch's current stream -> [n, 16000] float32 on the device (asynchronous)."""
+        n = self._n[slot]
+        if self.host_only:
+            raise RuntimeError("decode: this reader is host_only (no device twin)")
+        if out is None:
+            out = torch.empty((n, CLIP_SAMPLES), device=self.device, dtype=torch.float32)
+        elif out.shape != (n, CLIP_SAMPLES) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"decode: out must be a contiguous float32 [{n}, {CLIP_SAMPLES}] tensor on {self.device}")
+        if self.host_only:
+            raise RuntimeError("decode: this reader is host_only (no device twin)")
+        if n:
+            with torch.cuda.device(self.device):
+                nat.check(nat.lib.ww_wav_batch_decode(self._h, slot, int(bool(normalize)), C.c_void_p(out.data_ptr()),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    @staticmethod
+    def draw_crops(descs, status, n: int = CLIP_SAMPLES) -> None:
+        """pad_or_truncate's random crop (:79-81) for every file longer than `n` samples at 16 kHz, python `random` like the reference."""
+        n_out = -(-(descs["n_frames"] * descs["up"]) // np.maximum(1, descs["down"]))
+        for i in np.nonzero((status == 1) & (n_out > n))[0]:
+            descs["crop_start"][i] = random.randint(0, int(n_out[i]) - n)
+
+    def load(self, paths, normalize: bool = True, out: torch.Tensor | None = None, verbose: bool = True):
+        """read + crop draw + decode of one batch on the next slot -> (device tensor [B, 16000], ok mask).  Unreadable files
+        give a zero row and ok False, with the reference's message (:70)."""
+        if len(paths) > self.max_clips:
+            self._regrow(len(paths), max(self.max_raw_bytes, len(paths) * 2 * CLIP_SAMPLES + 4096))
+        slot = self.next_slot()
+        try:
+            descs, status = self.read(paths, slot)
+        except nat.NativeError as e:
+            if e.code != nat.WW_ENOSPACE:
+                raise
+            self._regrow(max(len(paths), self.max_clips), int(e.needed * 1.25) + 4096)
+            slot = self.next_slot()
+            descs, status = self.read(paths, slot)
+        self.draw_crops(descs, status)
+        ok = status == 1
+        if verbose and not ok.all():
+            for i in np.nonzero(~ok)[0][:8]:
+                print(f"Error loading {paths[i]}: {nat.WAV_STATUS.get(int(status[i]), status[i])}")
+        return self.decode(slot, normalize, out), ok
+
+    def _regrow(self, max_clips: int, max_raw_bytes: int) -> None:
+        if not self.host_only:
+            torch.cuda.synchronize(self.device)
+        self.close()
+        self.__init__(max_clips, max_raw_bytes, self.threads, self.slots, self.device, self.host_only)
+
+
+def probe(path) -> dict | None:
+    """Header of one WAV file (no GPU): {'n_frames', 'channels', 'sample_rate', 'format', 'data_offset', 'up', 'down'} or None."""
+    d = nat.ClipDesc()
+    if nat.lib.ww_wav_probe_host(os.fsencode(path), C.byref(d)) != 1:
+        return None
+    return {"n_frames": d.n_frames, "channels": d.channels, "sample_rate": d.sample_rate, "format": d.format, "data_offset": d.byte_offset,
+            "up": d.up, "down": d.down}
