@@ -26,6 +26,13 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 arithmetics; training_pipeline: augment -> log-mel -> step; training_3conv: the notebook's 3-conv model
   streaming     BASELINE configs[4] (256 microphones, 10 ms hop, hipGraph replay per hop): p50/p99 hop latency, hops/s
                 (rank 0, N = 1 only; measured after the timed region)
+  forward_3conv the notebook's 3-conv WakewordModel at the same batch: clips/s, per-stage ms, roofline of its conv stack
+  decode        K0 alone (sample bytes in HBM -> normalised clips), 16 kHz and 48 kHz
+  file_pipeline WAV files in a temporary directory -> logits (reader threads -> pinned staging -> H2D -> K0..K3): the file-fed rate,
+                to be read beside the reference's own published 453 clips/s (wakeword_training.ipynb:742)
+  gather        when a process group exists (N > 1, or WW_BENCH_FORCE_DIST=1 for a one-rank RCCL group): blocking latency of the
+                logits all-gather alone
+Environment: WW_BENCH_BACKEND=gloo is a REHEARSAL mode (ranks share GPUs, host-staged gather) and is labelled as such in the line.
 """
 import argparse
 import json
@@ -52,10 +59,16 @@ MFMA_F16_PEAK = 2.5e15                                 # flop/s, dense f16/bf16 
 METRIC = "1s/16kHz clips/sec end-to-end (mel+CNN+LSTM)"
 
 
-def pmc_traffic(kernel, batch, arch):
+def pmc_traffic(kernel, batch, arch, with_source=False):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json: FETCH_SIZE x2 +
     WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process;
-    the newest committed pass for this batch/arch is quoted, else null."""
+    the newest committed pass for this batch/arch is quoted (its file name goes into `traffic_source`), else null."""
+    if with_source:
+        for path in _pmc_files(arch):
+            v = _pmc_traffic_from(path, kernel, batch)
+            if v is not None:
+                return v, "profiles/" + os.path.basename(path)
+        return None, None
     import glob
     if batch != 4096:
         return None
@@ -71,6 +84,23 @@ def pmc_traffic(kernel, batch, arch):
         except Exception:
             continue
     return None
+
+
+def _pmc_files(arch):
+    import glob
+    pattern = "r*_pmc_traffic.json" if arch == "simple" else "r*_full_pmc_traffic.json"
+    return [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True) if arch != "simple" or "_full_" not in f]
+
+
+def _pmc_traffic_from(path, kernel, batch):
+    if batch != 4096:
+        return None
+    try:
+        k = json.load(open(path))["kernels"]
+        hits = [d["hbm_bytes_per_launch_corrected"] for name, d in k.items() if any(part in name for part in kernel.split("+"))]
+        return sum(hits) if hits else None
+    except Exception:
+        return None
 
 
 def pmc_busy(kernel, batch, arch):
@@ -136,7 +166,8 @@ def main():
     # WW_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share GPUs, the logits
     # all-gather goes through host memory); the driver's runs use RCCL ("nccl").
     backend = os.environ.get("WW_BENCH_BACKEND", "nccl")
-    rank, world, local = wdist.init_from_env(backend)
+    force_dist = os.environ.get("WW_BENCH_FORCE_DIST", "0") == "1"       # one rank, but with a real (RCCL) group around the step
+    rank, world, local = wdist.init_from_env(backend, force=force_dist)
     if backend == "gloo" and torch.cuda.is_available():
         local = local % torch.cuda.device_count()
     if world != max(1, args.gpus):
@@ -163,8 +194,8 @@ def main():
     model = model.to(dev).eval()
     packed = model.packed_weights()
 
-    # rank r holds clips [r*B, (r+1)*B) of the global batch; built from 256 distinct synthetic clips per rank
-    host = pkg.synth.make_clips_tiled(rank * B, B, unique=256)
+    # rank r holds clips [r*B, (r+1)*B) of the global batch: B DISTINCT synthetic clips (seed = clip index)
+    host = pkg.synth.make_clips(rank * B, B)
     pcm = torch.from_numpy(host).to(dev)
     ws = torch.empty(nat.check(nat.lib.ww_workspace_bytes(B, n_conv)), device=dev, dtype=torch.uint8)
     mel = torch.empty((B, 1, 80, 32), device=dev)
@@ -172,11 +203,8 @@ def main():
     scratch_bytes = nat.check(nat.lib.ww_cnn_scratch_bytes(B, n_conv))
     scratch = torch.empty(max(1, scratch_bytes), device=dev, dtype=torch.uint8)
     # logits / gathered are double-buffered: the all-gather of step k runs on RCCL's stream while step k+1 computes
-    logits2 = [torch.empty((B, 2), device=dev) for _ in range(2)]
-    gathered2 = [torch.empty((world * B, 2), device=dev) for _ in range(2)] if world > 1 else logits2
-    logits, gathered = logits2[0], gathered2[0]
-    pending = [None, None]
-    step_no = [0]
+    # (distributed.LogitsGatherPipeline: the same object tests/_rccl_child.py drives on a one-rank RCCL group)
+    pipe = wdist.LogitsGatherPipeline(B, dev)
 
     import ctypes as C
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
@@ -184,12 +212,7 @@ def main():
     st = C.c_void_p(stream.cuda_stream)
 
     def step(ev=None):
-        b = step_no[0] & 1
-        step_no[0] += 1
-        logits, gathered = logits2[b], gathered2[b]
-        if pending[b] is not None:          # the gather that last used this buffer pair (two steps ago) must be done
-            pending[b].wait()
-            pending[b] = None
+        logits = pipe.acquire()             # waits for the gather that last used this buffer pair (two steps ago)
         if ev: ev[0].record(stream)
         nat.check(nat.lib.ww_logmel_f32(p(pcm), B, 16000, 16000, 1, p(mel), st))
         if ev: ev[1].record(stream)
@@ -197,20 +220,11 @@ def main():
         if ev: ev[2].record(stream)
         nat.check(nat.lib.ww_lstm_fc_f32(p(pooled), B, p(packed), n_conv, p(logits), st))
         if ev: ev[3].record(stream)
-        if world > 1:
-            if backend == "gloo":
-                parts = [torch.empty((B, 2)) for _ in range(world)]
-                dist.all_gather(parts, logits.cpu())
-                gathered.copy_(torch.cat(parts))
-            else:
-                pending[b] = dist.all_gather_into_tensor(gathered, logits, async_op=True)
+        pipe.submit()                       # async all-gather of this step's logits (nothing without a process group)
 
     def fence():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-        if world > 1:
+        pipe.drain()
+        if pipe.active:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -225,9 +239,22 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
-    if world > 1:
+    if pipe.active:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # the exchange alone: blocking latency of one all-gather of [B, 2] logits (every rank takes part)
+    gather_us = None
+    if pipe.active and backend != "gloo":
+        g_out = torch.empty((world * B, 2), device=dev)
+        for _ in range(5):
+            dist.all_gather_into_tensor(g_out, pipe.logits[0])
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(50):
+            dist.all_gather_into_tensor(g_out, pipe.logits[0])
+        torch.cuda.synchronize()
+        gather_us = 1e6 * (time.perf_counter() - tg) / 50
 
     ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events])    # [steps, 3] K1,K2,K3
     k1_ms, k2_ms, k3_ms = [float(v) for v in ms.mean(axis=0)]
@@ -263,7 +290,7 @@ def main():
         fence()
         again = time.perf_counter() - t2
         ta = torch.tensor([again], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
-        if world > 1:
+        if pipe.active:
             dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         sustained["timed_region_again"] = {"steps": args.steps, "ms_per_step": 1e3 * float(ta.item()) / args.steps,
                                            "clips_per_s_per_gpu": B * args.steps / float(ta.item())}
@@ -305,19 +332,32 @@ def main():
         # matrix-pipe flops actually issued per algorithmic flop: 3 (split) x 2/3 for conv2 as Winograd F(2,3) along rows
         issue_mult = (3.0 * (2.0 / 3.0 if wino else 1.0)) if split else 1.0
         k2_peak = MFMA_F16_PEAK if split else MFMA_F32_PEAK
+        k2_kernels = (("cnn2w_kernel" if wino else "cnn2h16_kernel" if split else "cnn2_kernel") if args.arch == "simple" else
+                      ("cnn2w_kernel+cnn3w_kernel" if wino else "cnn2h16_kernel+cnn3h_kernel" if split else "cnn2_kernel+cnn3_kernel"))
+        k2_traffic, k2_traffic_src = pmc_traffic(k2_kernels, B, args.arch, with_source=True)
+        k1_traffic, k1_traffic_src = pmc_traffic("logmel_kernel", B, args.arch, with_source=True)
+        n_dev = torch.cuda.device_count()
+        if backend == "gloo" and world > 1:
+            exchange = f" -> gloo REHEARSAL of the logits all-gather, host-staged: {world} ranks on {min(world, n_dev)} GPU(s), not an RCCL measurement"
+        elif pipe.active:
+            exchange = f" -> RCCL all-gather of logits ({world}-rank group)"
+        else:
+            exchange = ""
         out = {
-            "metric": METRIC, "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC, "value": clips_per_s, "unit": "clips/s", "n_gpus": (world if not (backend == "gloo" and world > 1) else min(world, n_dev)), "ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 in/out/accumulate; conv and LSTM-gate GEMM products as f16x3 split (3 f16 MFMAs per fp32 product block, ~2^-21 rel.)" if split else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[2]: batch={B} 1 s/16 kHz clips per GPU, full log-mel + CNN + LSTM HIP forward "
-                            f"(K1 -> K2 -> K3{' -> RCCL all-gather of logits' if world > 1 else ''}), PCM and logits resident in HBM; "
+                            f"(K1 -> K2 -> K3{exchange}), {B} distinct synthetic clips per GPU (seed = clip index), PCM and logits resident in HBM; "
                             + ("SimpleWakewordModel (train_wakeword.py:28-49)" if args.arch == "simple"
                                else "3-conv WakewordModel (wakeword_training_script.py:141-184)") + ", random-init weights seed 1234",
                 "global_batch": world * B, "clips_per_gpu": B, "conv_math": conv_math, "logmel_math": logmel_math,
-                "parallelism": f"clips sharded over {world} GPU(s), replicated weights",
+                "parallelism": (f"clips sharded over {world} GPU(s), replicated weights" if not (backend == "gloo" and world > 1) else
+                                f"gloo rehearsal: {world} ranks sharing {min(world, n_dev)} GPU(s), replicated weights"),
+                "backend": (backend if pipe.active else None),
             },
             "roofline": {
                 "kernel": ("cnn2w_kernel (conv1 + conv2 + ReLU + avg-pool; conv2 as 1-D Winograd F(2,3) along rows, split-precision v_mfma_f32_16x16x32_f16 x3)" if wino else
@@ -327,8 +367,7 @@ def main():
                                 "cnn2h16_kernel<false> + cnn3h_kernel (direct split-precision convs, f16 hi/lo intermediate in HBM)" if split else
                                 "cnn2_kernel<false> + cnn3_kernel (exact f32)"),
                 "bound": "mfma", "achieved": k2_ach / 1e12, "peak": k2_peak / 1e12, "unit": "TFLOP/s",
-                "frac": k2_ach / k2_peak, "traffic": pmc_traffic(("cnn2w_kernel" if wino else "cnn2h16_kernel" if split else "cnn2_kernel") if args.arch == "simple" else
-                                                 ("cnn2w_kernel+cnn3w_kernel" if wino else "cnn2h16_kernel+cnn3h_kernel" if split else "cnn2_kernel+cnn3_kernel"), B, args.arch),
+                "frac": k2_ach / k2_peak, "traffic": k2_traffic, "traffic_source": k2_traffic_src,
                 "flops_per_launch": k2_flops, "avg_launch_ms": k2_ms,
                 "note": (f"achieved = ALGORITHMIC fp32 flops of the direct convolution; the kernel issues {issue_mult:.1f} f16 MFMA flops per "
                          "algorithmic flop (3 per product block for fp32-level accuracy"
@@ -338,7 +377,7 @@ def main():
             "stages": {
                 "K1_logmel": {"avg_ms": k1_ms, "bound": "hbm", "achieved_GBps": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / 1e9,
                               "peak_GBps": HBM_PEAK / 1e9, "frac": K1_BYTES_PER_CLIP * B / (k1_ms * 1e-3) / HBM_PEAK,
-                              "clips_per_s": B / (k1_ms * 1e-3), "traffic": pmc_traffic("logmel_kernel", B, args.arch),
+                              "clips_per_s": B / (k1_ms * 1e-3), "traffic": k1_traffic, "traffic_source": k1_traffic_src,
                               "f32_vector_frac": K1_FLOPS_PER_CLIP * B / (k1_ms * 1e-3) / MFMA_F32_PEAK,
                               "math": logmel_math + (" (float32 FFT kernel + the launch that redoes marked clips in float64; none of the "
                                                      "benchmark's sine+noise clips is marked)" if logmel_math == "auto" else ""),
@@ -356,6 +395,10 @@ def main():
             "device": nat.device_info(),
             "sync_timeouts": int(nat.lib.ww_sync_timeouts()),      # bounded in-kernel waits that expired: must be 0
         }
+        if gather_us is not None:
+            out["gather"] = {"collective": "all_gather_into_tensor of [B, 2] float32 logits per rank (RCCL)", "ranks": world,
+                             "bytes_per_rank": B * 8, "blocking_latency_us": gather_us,
+                             "note": "in the timed step the gather is asynchronous and overlaps the next step's kernels"}
         if sustained is not None:
             sustained["clips_per_s"] = sustained.pop("clips_per_s_per_gpu") * world
             sustained["timed_region_again"]["clips_per_s"] = sustained["timed_region_again"].pop("clips_per_s_per_gpu") * world
@@ -395,8 +438,15 @@ def main():
             out["training_3conv"] = bench_train.measure(batch=2048, steps=3, device=dev.index, arch="full", cpu_sample=16)
             out["training_3conv"]["exact_fp32_ms_per_step"] = bench_train.measure(batch=2048, steps=2, device=dev.index, arch="full", math="f32", cpu_sample=4)["ms_per_step"]
             bench_train.ops_reset_train_math()
+            # the notebook's model in inference (driver-run figure for SURVEY A11 / 8(f).3's forward half)
+            import bench_forward
+            out["forward_3conv"] = bench_forward.measure(batch=B, steps=10, device=dev.index, pcm=pcm)
+            # K0 alone, and WAV files -> logits
+            import bench_files
+            out["decode"] = bench_files.measure_decode(batch=B, steps=10, device=dev.index)
+            out["file_pipeline"] = bench_files.measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=dev.index)
         print(json.dumps(out))
-    if world > 1:
+    if pipe.active:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -86,10 +86,10 @@ WW_API int ww_sync_timeouts(void);
  *                       from the clip's max |x| and the layers' l1 bounds, so no f16 half overflows or goes subnormal. */
 #define WW_CONV_MATH_F32 0
 #define WW_CONV_MATH_F16X3 1
-/*   WW_CONV_MATH_F16X3_DIRECT  F16X3 with every convolution in its direct (implicit-GEMM) form.  Under F16X3 the 2-conv model's
- *                       conv2 -- 98 % of its flops -- runs as a one-dimensional Winograd F(2,3) along the image rows (1.5x
- *                       fewer matrix instructions; the transforms are fp32 adds on the activations and exact-in-double
- *                       combinations of the weights); the 3-conv model uses the direct form under both. */
+/*   WW_CONV_MATH_F16X3_DIRECT  F16X3 with every convolution in its direct (implicit-GEMM) form.  Under F16X3 conv2 of BOTH models and
+ *                       conv3 of the 3-conv model run as a one-dimensional Winograd F(2,3) along the image rows (1.5x fewer
+ *                       matrix instructions; the transforms are fp32 adds on the activations and exact-in-double combinations
+ *                       of the weights); under F16X3_DIRECT every convolution of both models is direct. */
 #define WW_CONV_MATH_F16X3_DIRECT 2
 WW_API int ww_set_conv_math(int mode);
 WW_API int ww_get_conv_math(void);
@@ -102,8 +102,12 @@ WW_API int ww_get_conv_math(void);
  *   WW_LOGMEL_MATH_F32   float32 FFT for every clip (the throughput kernel)
  *   WW_LOGMEL_MATH_F64   window product, FFT and real-input split in float64 for every clip (~4x the time)
  *   WW_LOGMEL_MATH_AUTO  the float32 kernel, which marks the clips that have a live (unclamped) mel band on its rounding
- *                        floor; a second launch redoes exactly those clips in float64.  <= 1e-4 dB against the float64
- *                        reference for any signal; costs one near-empty launch when no clip is marked. */
+ *                        floor; a second launch redoes exactly those clips in float64.  MEASURED, not proven: <= 1.5e-5 dB
+ *                        against the float64 reference on every noise-free test signal of tests/test_gpu_parity.py (the marking
+ *                        threshold, band/frame energy ratio 1e-5, sits 2.7x above the boundary 10^-5.43 found on that sample,
+ *                        profiles/r02_diag_floor.log).  Cost: one near-empty launch when no clip is marked; a marked clip costs
+ *                        the float64 kernel (~3x): clean-speech / digitally silent data pays up to K1 x3 (bench line:
+ *                        stages.K1_logmel.noise_free_batch). */
 #define WW_LOGMEL_MATH_F32 0
 #define WW_LOGMEL_MATH_F64 1
 #define WW_LOGMEL_MATH_AUTO 2
@@ -313,13 +317,21 @@ typedef struct ww_train_grads {  /* outputs, overwritten (not accumulated) */
     float* fc_weight;            /* [2, 256] */
     float* fc_bias;              /* [2] */
 } ww_train_grads;
-WW_API int64_t ww_train_workspace_bytes(int64_t n, int32_t n_conv);
-/* mel_dev [n][80][width]; p_lstm / p_fc: drop probabilities (0 = eval-mode arithmetic); workspace_dev >= ww_train_workspace_bytes,
- * 256-byte aligned, must stay untouched until the matching ww_train_backward_f32 has run; logits_dev [n][2]. */
+/* The arithmetic is part of every call of a step (ABI 4): train_math = WW_TRAIN_MATH_F32 | WW_TRAIN_MATH_F16X3 (below), or
+ * WW_TRAIN_MATH_DEFAULT = the process-wide ww_set_train_math value read at that call.  The workspace LAYOUT depends on it (0.23 GB under
+ * F16X3, 2.7 GB under F32 for 4096 clips of the 2-conv model), so forward and backward also take the size of the buffer they were given
+ * and return WW_EINVAL when it is smaller than ww_train_workspace_bytes(n, n_conv, train_math) -- a mode switch between the size query and
+ * the launch cannot write past the buffer; a backward under another mode than its forward is WW_EINVAL too. */
+#define WW_TRAIN_MATH_DEFAULT (-1)
+WW_API int64_t ww_train_workspace_bytes(int64_t n, int32_t n_conv, int32_t train_math);
+/* mel_dev [n][80][width]; p_lstm / p_fc: drop probabilities (0 = eval-mode arithmetic); workspace_dev: workspace_bytes >=
+ * ww_train_workspace_bytes bytes, 256-byte aligned, must stay untouched until the matching ww_train_backward_f32 has run; logits_dev [n][2]. */
 WW_API int ww_train_forward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params, float p_lstm,
-                                float p_fc, uint64_t seed, void* workspace_dev, float* logits_dev, ww_stream_t stream);
+                                float p_fc, uint64_t seed, int32_t train_math, void* workspace_dev, int64_t workspace_bytes,
+                                float* logits_dev, ww_stream_t stream);
 WW_API int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params,
-                                 const float* dlogits_dev, void* workspace_dev, const ww_train_grads* grads, ww_stream_t stream);
+                                 const float* dlogits_dev, int32_t train_math, void* workspace_dev, int64_t workspace_bytes,
+                                 const ww_train_grads* grads, ww_stream_t stream);
 /* Diagnostic: the dropout factors (0 or 1 / (1 - p)) the last forward on this workspace applied to the layer-0 output and to
  * fc's input, [n][256] each -- lets a test replay the step in another framework with the same masks. */
 WW_API int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, float* mask0_dev, float* mask1_dev, ww_stream_t stream);
@@ -330,15 +342,14 @@ WW_API int ww_train_packed_image(const void* workspace_dev, int64_t n, int32_t n
  * mask_last_dev [n][80][32][C/8] bytes, bit c of the position = [relu(last conv)[c] > 0] (C = 64 | 128, byte cb = channels 8 cb ..), in canonical
  * order (the kernels' own image holds the accumulator ballots); sign1_dev [n][80][32] words, bit c = [relu(conv1)[c] > 0]. */
 WW_API int ww_train_bit_images(const void* workspace_dev, int64_t n, int32_t n_conv, uint8_t* mask_last_dev, uint32_t* sign1_dev, ww_stream_t stream);
-/* Arithmetic of the training step's convolution kernels, process-wide (the head is always exact fp32):
+/* Arithmetic of the training step's convolution kernels (the head is always exact fp32); ww_set_train_math sets the process-wide DEFAULT that
+ * WW_TRAIN_MATH_DEFAULT resolves to:
  *   WW_TRAIN_MATH_F32    exact fp32 matrix instructions throughout (v_mfma_f32_32x32x2_f32)
  *   WW_TRAIN_MATH_F16X3  (default) the conv stack in split precision on the f16 matrix instructions, for both models: forward = the
  *                        inference kernels with the ReLU masks as extra outputs (bit images); backward of the last conv: one operand
  *                        is the 0/1 mask, exact in f16, the other is carried as two f16 halves; below it both operands as two halves;
  *                        conv1's weight gradient in double on the f64 matrix instructions.  The head runs as under F32.
- *                        Gradients agree with F32 to the 2^-22 of the split.  A step's workspace query, forward and backward must run under
- *                        the same mode (the workspace layout depends on it: 0.23 GB instead of 2.7 GB for 4096 clips of the 2-conv model);
- *                        ww_train_backward_f32 returns WW_EINVAL for a workspace whose forward ran under the other mode. */
+ *                        Gradients agree with F32 to the 2^-22 of the split. */
 #define WW_TRAIN_MATH_F32 0
 #define WW_TRAIN_MATH_F16X3 1
 WW_API int ww_set_train_math(int mode);

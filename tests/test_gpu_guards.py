@@ -304,13 +304,26 @@ from wakeword_jupyterlab_amd import ops, _native as nat
 assert nat.LIB_PATH.endswith("libwakeword_amd_spin1.so"), nat.LIB_PATH
 dev = torch.device("cuda", 0)
 res = {}
-for arch, n_conv in (("simple", 2), ("full", 3)):
-    packed = torch.from_numpy(ops.pack_state_dict(pkg.synth.make_state_dict(arch, seed=3))).to(dev)
-    x = torch.from_numpy((np.random.default_rng(0).standard_normal((700, 1, 80, 32)) * 15 - 35).astype(np.float32)).to(dev)
-    pooled = ops.cnn_pool(x, packed, n_conv)
+x = torch.from_numpy((np.random.default_rng(0).standard_normal((700, 1, 80, 32)) * 15 - 35).astype(np.float32)).to(dev)
+for math in ("f16x3", "f16x3d"):                     # cnn2w / cnn3w (Winograd) and cnn2h16 / cnn3h (direct)
+    ops.set_conv_math(math)
+    for arch, n_conv in (("simple", 2), ("full", 3)):
+        packed = torch.from_numpy(ops.pack_state_dict(pkg.synth.make_state_dict(arch, seed=3))).to(dev)
+        pooled = ops.cnn_pool(x, packed, n_conv)
+        torch.cuda.synchronize()
+        res[math + "/" + arch] = {"nan_rows": int(torch.isnan(pooled).all(dim=1).sum()), "finite_rows": int(torch.isfinite(pooled).all(dim=1).sum()),
+                                  "rows": int(pooled.shape[0])}
+# the training forwards (cnn2w_kernel<2>, cnn2w_kernel<3> + cnn3w_kernel<true>: the instantiations with the bit-image outputs)
+ops.set_conv_math("f16x3"); ops.set_train_math("f16x3")
+for arch in ("simple", "full"):
+    m = (pkg.SimpleWakewordModel() if arch == "simple" else pkg.WakewordModel())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in pkg.synth.make_state_dict(arch, seed=3).items()})
+    m = m.to(dev).train()
+    with torch.no_grad():
+        logits = m(x)
     torch.cuda.synchronize()
-    res[arch] = {"nan_rows": int(torch.isnan(pooled).all(dim=1).sum()), "finite_rows": int(torch.isfinite(pooled).all(dim=1).sum()),
-                 "rows": int(pooled.shape[0])}
+    res["train/" + arch] = {"nan_rows": int(torch.isnan(logits).all(dim=1).sum()), "finite_rows": int(torch.isfinite(logits).all(dim=1).sum()),
+                            "rows": int(logits.shape[0])}
 res["timeouts"] = int(nat.lib.ww_sync_timeouts())
 print("RESULT " + json.dumps(res))
 """
@@ -319,7 +332,9 @@ print("RESULT " + json.dumps(res))
 def test_expired_wait_poisons_the_outputs_with_nan():
     """Diagnostic twin of the library (csrc/Makefile: -DWW_FLAG_SPINS=1): every bounded wait of the conv kernel gives up after
     one poll, i.e. the producer / consumer protocol is broken on purpose.  Every workgroup that saw an expired wait must
-    overwrite ALL its pooled features with NaN and the counter must say so; rows are either all-NaN or all-finite."""
+    overwrite ALL its pooled features with NaN and the counter must say so; rows are either all-NaN or all-finite.  Covered: the
+    Winograd and the direct split-precision kernels of both models, and the training forwards (the instantiations that also write
+    the ReLU bit images), whose logits must then be NaN for the poisoned clips."""
     twin = os.path.join(ROOT, "wakeword-jupyterlab_amd", "csrc", "build", "libwakeword_amd_spin1.so")
     assert os.path.exists(twin), "build the diagnostic twin: make -C wakeword-jupyterlab_amd/csrc"
     env = dict(os.environ, WW_LIB_OVERRIDE=twin, WW_ROOT=ROOT, WW_CONV_MATH="f16x3")
@@ -327,7 +342,7 @@ def test_expired_wait_poisons_the_outputs_with_nan():
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["timeouts"] > 0
-    for arch in ("simple", "full"):
-        r = res[arch]
-        assert r["nan_rows"] > 0, r                                   # the broken run cannot be consumed silently
-        assert r["nan_rows"] + r["finite_rows"] == r["rows"], r        # never a half-written clip
+    for key in ("f16x3/simple", "f16x3/full", "f16x3d/simple", "f16x3d/full", "train/simple", "train/full"):
+        r = res[key]
+        assert r["nan_rows"] > 0, (key, r)                                   # the broken run cannot be consumed silently
+        assert r["nan_rows"] + r["finite_rows"] == r["rows"], (key, r)        # never a half-written clip

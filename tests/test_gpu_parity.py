@@ -2,6 +2,8 @@
 
 Tolerances are the ones BASELINE.json's north_star states: 1e-4 dB on log-mel values, 1e-3 on logits.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -96,6 +98,52 @@ def _clean_signals():
                      (np.arange(16000) == 8000).astype(np.float64), np.sign(np.sin(2 * np.pi * 100 * t)),
                      np.sin(2 * np.pi * 7400.0 * t) + 1e-3 * np.sin(2 * np.pi * 250.0 * t),
                      np.sin(2 * np.pi * 150.0 * t) * (np.arange(16000) < 6000)]).astype(np.float32)
+
+
+def _real_world_clean_signals():
+    """Families real WAV files produce and the six above do not: 16-bit-quantised content (a quantisation floor
+    ~98 dB under full scale), a DC offset with weak content, energy at Nyquist (bin 1024 has zero mel weight: the frame energy seen
+    through the mel bands under-counts it), hard clipping, chirps -- and a quantised tone that is also very quiet (few LSBs)."""
+    t = np.arange(16000) / 16000.0
+    q16 = lambda v: np.round(np.clip(v, -1, 1 - 2.0 ** -15) * 32768.0) / 32768.0       # what a PCM-16 file holds  # noqa: E731
+    chirp = lambda f0, f1: np.sin(2 * np.pi * (f0 * t + 0.5 * (f1 - f0) * t * t))      # noqa: E731
+    sigs = [
+        q16(0.5 * np.sin(2 * np.pi * 440.0 * t)),                                       # quantised tone
+        q16(0.3 * np.sin(2 * np.pi * 1234.5 * t) + 0.2 * np.sin(2 * np.pi * 310.0 * t)),  # quantised tone pair
+        q16(3.0 / 32768.0 * np.sin(2 * np.pi * 700.0 * t)),                             # three LSBs of signal
+        0.5 + 1e-3 * np.sin(2 * np.pi * 600.0 * t),                                     # DC offset, weak content
+        q16(0.25 + 2e-3 * np.sin(2 * np.pi * 2500.0 * t)),                              # the same, quantised
+        0.8 * np.cos(np.pi * np.arange(16000)) + 1e-3 * np.sin(2 * np.pi * 900.0 * t),  # Nyquist tone + weak content
+        0.8 * np.cos(np.pi * np.arange(16000)),                                         # Nyquist tone alone (mel sees only leakage)
+        np.clip(3.0 * np.sin(2 * np.pi * 220.0 * t), -1.0, 1.0),                        # hard clipping
+        q16(np.clip(1.7 * np.sin(2 * np.pi * 523.25 * t) * (t > 0.2), -1.0, 1.0)),      # clipped, gated, quantised
+        chirp(100.0, 7000.0),                                                           # fast chirp over the band
+        chirp(3000.0, 3050.0) * 0.05,                                                   # slow, quiet chirp
+        q16(0.4 * chirp(200.0, 3800.0)),                                                # quantised chirp
+    ]
+    return np.stack(sigs).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", ["auto", "f64", "f32"])
+def test_logmel_real_world_clean_families(ops, dev, mode):
+    """auto and f64 must meet north_star's 1e-4 dB on every family; the plain-f32 run is recorded for the calibration (it may miss it:
+    that is what auto mode is for) and must stay finite inside [-80, 0]."""
+    x = _real_world_clean_signals()
+    ref = mel_oracle.logmel_batch(x, normalize=True)
+    ops.set_logmel_math(mode)
+    try:
+        out = ops.logmel(torch.from_numpy(x).to(dev), True).cpu().numpy()
+    finally:
+        ops.set_logmel_math("auto")
+    err = np.abs(out - ref).max(axis=(1, 2, 3))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, f"clean_families_{mode}.json"), "w") as f:
+            json.dump({"mode": mode, "max_abs_err_dB_per_signal": [float(e) for e in err]}, f)
+    assert np.isfinite(out).all() and out.min() >= -80.0 and np.all(out.max(axis=(1, 2, 3)) == 0.0)
+    if mode != "f32":
+        assert err.max() <= MEL_TOL, err
 
 
 @pytest.mark.parametrize("mode", ["auto", "f64"])

@@ -213,6 +213,30 @@ def test_compute_entry_points_fail_loudly_without_a_gpu():
         pkg.AudioProcessor().audio_to_mel(np.ones(16000, np.float32))
 
 
+def test_training_workspace_size_is_checked_against_the_mode_of_the_call():
+    """the workspace layout follows the arithmetic (0.23 GB vs 2.7 GB at 4096 clips), so the mode and the buffer size are
+    arguments of every call of a step; a buffer sized for the other mode is WW_EINVAL before anything is launched (no GPU needed)."""
+    small, large = nat.lib.ww_train_workspace_bytes(4096, 2, 1), nat.lib.ww_train_workspace_bytes(4096, 2, 0)
+    assert 0 < small < 0.3e9 < 2e9 < large
+    assert nat.lib.ww_train_workspace_bytes(4096, 2, -1) == small                 # default mode of a fresh process: f16x3
+    assert nat.lib.ww_train_workspace_bytes(4096, 2, 7) == nat.WW_EINVAL
+    fake = np.zeros(1024, np.float32)
+    base = (fake.ctypes.data + 255) // 256 * 256
+    tp = nat.TrainParams()
+    tp.n_conv, tp.hidden = 2, 256
+    for i in range(2):
+        tp.conv_weight[i] = tp.conv_bias[i] = tp.lstm_weight_ih[i] = tp.lstm_bias_ih[i] = tp.lstm_bias_hh[i] = base
+    tp.fc_weight = tp.fc_bias = base
+    args = (base, 4096, 32, C.byref(tp), 0.0, 0.0, 1)
+    assert nat.lib.ww_train_forward_f32(*args, 0, base, small, base, None) == nat.WW_EINVAL          # f32 layout into an f16x3-sized buffer
+    assert b"need" in nat.lib.ww_last_error()
+    assert nat.lib.ww_train_forward_f32(*args, 5, base, large, base, None) == nat.WW_EINVAL          # unknown mode
+    tg = nat.TrainGrads()
+    assert nat.lib.ww_train_backward_f32(base, 4096, 32, C.byref(tp), base, 0, base, small, C.byref(tg), None) == nat.WW_EINVAL
+    if not HAS_GPU:                                                                                   # large enough: only the device is missing
+        assert nat.lib.ww_train_forward_f32(*args, 1, base, small, base, None) == nat.WW_ENODEVICE
+
+
 def test_argument_checks_come_before_device_checks():
     buf = np.zeros(16, np.float32)
     assert nat.lib.ww_logmel_f32(buf.ctypes.data, 1, 16000, 20000, 1, buf.ctypes.data, None) == nat.WW_EINVAL

@@ -118,11 +118,11 @@ PROTOTYPES = {
     "ww_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "ww_model_forward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_forward_pcm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ww_train_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
-    "ww_train_forward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(TrainParams), C.c_float, C.c_float, C.c_uint64, C.c_void_p,
-                                       C.c_void_p, C.c_void_p]),
-    "ww_train_backward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(TrainParams), C.c_void_p, C.c_void_p, C.POINTER(TrainGrads),
-                                        C.c_void_p]),
+    "ww_train_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "ww_train_forward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(TrainParams), C.c_float, C.c_float, C.c_uint64, C.c_int32,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ww_train_backward_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(TrainParams), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                        C.POINTER(TrainGrads), C.c_void_p]),
     "ww_train_masks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ww_train_packed_image": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "ww_train_bit_images": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

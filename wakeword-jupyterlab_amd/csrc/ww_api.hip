@@ -346,18 +346,34 @@ static int check_train(const float* mel, int64_t n, int32_t width, const ww_trai
     return WW_OK;
 }
 
-int64_t ww_train_workspace_bytes(int64_t n, int32_t n_conv) {
+// WW_TRAIN_MATH_DEFAULT -> the process-wide setting, read ONCE per call (the caller should then hand the resolved value to the other half)
+static int resolve_train_math(int32_t mode, int* out) {
+    if (mode == WW_TRAIN_MATH_DEFAULT) mode = g_train_math;
+    if (mode != WW_TRAIN_MATH_F32 && mode != WW_TRAIN_MATH_F16X3)
+        return fail(WW_EINVAL, "train math %d: expected WW_TRAIN_MATH_F32, WW_TRAIN_MATH_F16X3 or WW_TRAIN_MATH_DEFAULT", mode);
+    *out = mode;
+    return WW_OK;
+}
+
+int64_t ww_train_workspace_bytes(int64_t n, int32_t n_conv, int32_t train_math) {
     if (n < 0 || n > (int64_t(1) << 24) || (n_conv != 2 && n_conv != 3)) return fail(WW_EINVAL, "bad training workspace query");
-    return train_workspace_bytes(n, n_conv);
+    int mode;
+    if (int rc = resolve_train_math(train_math, &mode)) return rc;
+    return train_workspace_bytes(n, n_conv, mode);
 }
 
 int ww_train_forward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params, float p_lstm, float p_fc,
-                         uint64_t seed, void* workspace_dev, float* logits_dev, ww_stream_t stream) {
+                         uint64_t seed, int32_t train_math, void* workspace_dev, int64_t workspace_bytes, float* logits_dev, ww_stream_t stream) {
+    int mode;
+    if (int rc = resolve_train_math(train_math, &mode)) return rc;
     if (int rc = check_train(mel_dev, n, width, params, workspace_dev)) return rc;
+    if (workspace_bytes < train_workspace_bytes(n, params->n_conv, mode))
+        return fail(WW_EINVAL, "training workspace of %lld bytes: %lld clips of the %d-conv model under train math %d need %lld",
+                    (long long)workspace_bytes, (long long)n, params->n_conv, mode, (long long)train_workspace_bytes(n, params->n_conv, mode));
     if (!logits_dev) return fail(WW_EINVAL, "null logits pointer");
     if (!(p_lstm >= 0.f && p_lstm < 1.f) || !(p_fc >= 0.f && p_fc < 1.f)) return fail(WW_EINVAL, "drop probabilities must lie in [0, 1)");
     if (int rc = require_gfx950()) return rc;
-    return train_forward(mel_dev, n, width, params, p_lstm, p_fc, seed, workspace_dev, logits_dev, static_cast<hipStream_t>(stream));
+    return train_forward(mel_dev, n, width, params, p_lstm, p_fc, seed, mode, workspace_dev, workspace_bytes, logits_dev, static_cast<hipStream_t>(stream));
 }
 
 int ww_train_masks(const void* workspace_dev, int64_t n, int32_t n_conv, float* mask0_dev, float* mask1_dev, ww_stream_t stream) {
@@ -377,8 +393,13 @@ int ww_train_bit_images(const void* workspace_dev, int64_t n, int32_t n_conv, ui
 }
 
 int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width, const ww_train_params* params, const float* dlogits_dev,
-                          void* workspace_dev, const ww_train_grads* grads, ww_stream_t stream) {
+                          int32_t train_math, void* workspace_dev, int64_t workspace_bytes, const ww_train_grads* grads, ww_stream_t stream) {
+    int mode;
+    if (int rc = resolve_train_math(train_math, &mode)) return rc;
     if (int rc = check_train(mel_dev, n, width, params, workspace_dev)) return rc;
+    if (workspace_bytes < train_workspace_bytes(n, params->n_conv, mode))
+        return fail(WW_EINVAL, "training workspace of %lld bytes: %lld clips of the %d-conv model under train math %d need %lld",
+                    (long long)workspace_bytes, (long long)n, params->n_conv, mode, (long long)train_workspace_bytes(n, params->n_conv, mode));
     if (!dlogits_dev || !grads) return fail(WW_EINVAL, "null argument");
     for (int i = 0; i < params->n_conv; ++i)
         if (!grads->conv_weight[i] || !grads->conv_bias[i]) return fail(WW_EINVAL, "null gradient pointer");
@@ -386,7 +407,7 @@ int ww_train_backward_f32(const float* mel_dev, int64_t n, int32_t width, const 
         if (!grads->lstm_weight_ih[i] || !grads->lstm_bias[i]) return fail(WW_EINVAL, "null gradient pointer");
     if (!grads->fc_weight || !grads->fc_bias) return fail(WW_EINVAL, "null gradient pointer");
     if (int rc = require_gfx950()) return rc;
-    return train_backward(mel_dev, n, width, params, dlogits_dev, workspace_dev, grads, static_cast<hipStream_t>(stream));
+    return train_backward(mel_dev, n, width, params, dlogits_dev, mode, workspace_dev, workspace_bytes, grads, static_cast<hipStream_t>(stream));
 }
 
 int ww_streamer_create(int32_t n_mics, int32_t hop_samples, const float* packed_dev, int32_t n_conv,

@@ -301,6 +301,10 @@ __device__ __forceinline__ void flag_signal(uint32_t* f) {
 #ifndef WW_FLAG_SPINS
 #define WW_FLAG_SPINS (1 << 22)
 #endif
+// Bounded wait on an LDS counter: 2^22 polls x s_sleep(1) ~ 0.2-0.4 s.  The bound is a poll count, not a clock, on purpose: all waves of a
+// workgroup are co-resident on one CU (and are context-switched together), so a partner wave cannot be "legitimately slow" by more than
+// the work of one tile step (microseconds); and a clock-bounded slow path behind the poll loop (s_memrealtime, tried in round 3) is
+// inlined at every wait site and cost cnn2w_kernel<1> two more VGPR spills at its 168-register cap.
 __device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target, uint32_t* bad) {
 #pragma unroll 1
     for (int spin = 0; spin < WW_FLAG_SPINS; ++spin) {
@@ -1462,6 +1466,16 @@ int launch_cnn3_f32_store(const float* mid2, int64_t n, int width, const float* 
     return WW_OK;
 }
 
+// Experiment knob (WW_CNN3_SUBBATCH, read once): clips per conv2 -> conv3 sub-batch of the 3-conv model's Winograd path.
+static int64_t cnn3_subbatch() {
+    static const int64_t v = [] {
+        const char* e = getenv("WW_CNN3_SUBBATCH");
+        const long long x = e ? atoll(e) : 0;
+        return int64_t(x > 0 ? x : 0);
+    }();
+    return v;
+}
+
 int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed, int n_conv, void* scratch,
                     float* pooled, hipStream_t stream) {
     if (n == 0) return WW_OK;
@@ -1484,14 +1498,21 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
                 return WW_OK;
             }
             float* apw = reinterpret_cast<float*>(static_cast<char*>(scratch) + mid_bytes(n));
-            hipLaunchKernelGGL(cnn2w_kernel<false>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
-                               packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
-                               packed + L.range, static_cast<float*>(scratch), apw, static_cast<uint16_t*>(nullptr), static_cast<uint16_t*>(nullptr));
-            WW_HIP(hipGetLastError());
-            hipLaunchKernelGGL(cnn3w_kernel<false>, dim3(grid1), dim3(512), kC3wLds, stream, static_cast<const float*>(scratch),
-                               static_cast<const float*>(apw), int(n), width, reinterpret_cast<const u32x4*>(packed + L.conv3_hw),
-                               packed + L.conv3_hws, packed + L.conv3_b, pooled, static_cast<uint16_t*>(nullptr));
-            WW_HIP(hipGetLastError());
+            // conv2 -> conv3 over sub-batches that reuse the FRONT of the scratch buffer: the 655 KB per clip of relu(conv2) are then
+            // written and read back inside the 256 MB Infinity Cache instead of going through HBM (cnn3_subbatch() clips; 0 = one pass)
+            const int64_t sub = cnn3_subbatch() > 0 ? cnn3_subbatch() : n;
+            for (int64_t s0 = 0; s0 < n; s0 += sub) {
+                const int64_t cnt = n - s0 < sub ? n - s0 : sub;
+                const int g = int(cnt < cus ? cnt : cus);
+                hipLaunchKernelGGL(cnn2w_kernel<false>, dim3(g), dim3(768), kCWLds, stream, mel + s0 * 80 * width, int(cnt), width, w1h,
+                                   packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,
+                                   packed + L.range, static_cast<float*>(scratch), apw, static_cast<uint16_t*>(nullptr), static_cast<uint16_t*>(nullptr));
+                WW_HIP(hipGetLastError());
+                hipLaunchKernelGGL(cnn3w_kernel<false>, dim3(g), dim3(512), kC3wLds, stream, static_cast<const float*>(scratch),
+                                   static_cast<const float*>(apw), int(cnt), width, reinterpret_cast<const u32x4*>(packed + L.conv3_hw),
+                                   packed + L.conv3_hws, packed + L.conv3_b, pooled + s0 * 128, static_cast<uint16_t*>(nullptr));
+                WW_HIP(hipGetLastError());
+            }
             return WW_OK;
         }
         if (n_conv == 2) {

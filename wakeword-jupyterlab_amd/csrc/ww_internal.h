@@ -135,15 +135,15 @@ int launch_lstm_fc(const float* pooled, int64_t n, const float* packed, int n_co
                    float* prob /*nullable*/, hipStream_t stream);
 
 // training step (ww_train.hip)
-int64_t train_workspace_bytes(int64_t n, int n_conv);
-int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
-                  float* logits, hipStream_t st);
+int64_t train_workspace_bytes(int64_t n, int n_conv, int mode);
+int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, int mode,
+                  void* workspace, int64_t workspace_bytes, float* logits, hipStream_t st);
 int train_masks(const void* workspace, int64_t n, int n_conv, float* mask0, float* mask1, hipStream_t st);
 int train_packed_image(const void* workspace, int64_t n, int n_conv, float* img, hipStream_t st);
 int train_bit_images(const void* workspace, int64_t n, int n_conv, uint8_t* mask_last, uint32_t* sign1, hipStream_t st);
 int launch_decode_mask_image(const uint32_t* img, int64_t n, int C, uint8_t* out, hipStream_t st);
-int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
-                   const ww_train_grads* g, hipStream_t st);
+int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, int mode, void* workspace,
+                   int64_t workspace_bytes, const ww_train_grads* g, hipStream_t st);
 
 int train_math_mode();   // 0 exact fp32, 1 split-precision conv backward where a kernel exists (ww_train_h.hip)
 int launch_pack_conv_h_dev(const ww_train_params* p, float* img, hipStream_t st);

@@ -598,7 +598,7 @@ static int workspace_mode(const void* ws) {            // -1: unknown (never see
     return -1;
 }
 
-static TrainWs carve_train(void* base, int64_t n, int n_conv, int mode = -1) {
+static TrainWs carve_train(void* base, int64_t n, int n_conv, int mode) {
     TrainWs w{};
     float* p = static_cast<float*>(base);
     int64_t o = 0;
@@ -606,7 +606,7 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv, int mode = -1) {
     const int c_last = n_conv == 3 ? 128 : 64;
     // the activations the exact-fp32 kernels keep; under the split arithmetic only the 3-conv model's relu(conv2) is stored (the rest
     // travels as bit images), so the layout depends on the arithmetic: query, forward and backward must agree on ww_set_train_math
-    const bool split = (mode >= 0 ? mode : train_math_mode()) == WW_TRAIN_MATH_F16X3;
+    const bool split = (mode >= 0 ? mode : train_math_mode()) == WW_TRAIN_MATH_F16X3;   // -1 (diagnostics on a workspace nobody noted): the process default
     w.mid2 = (!split || n_conv == 3) ? take(n * kTH * 64 * kTW) : nullptr;
     w.mid3 = (n_conv == 3 && !split) ? take(n * kTH * 128 * kTW) : nullptr;
     w.dz2 = n_conv == 3 ? take(n * kTH * 64 * kTW) : nullptr;
@@ -630,7 +630,7 @@ static TrainWs carve_train(void* base, int64_t n, int n_conv, int mode = -1) {
     return w;
 }
 
-int64_t train_workspace_bytes(int64_t n, int n_conv) { return carve_train(nullptr, n, n_conv).total; }
+int64_t train_workspace_bytes(int64_t n, int n_conv, int mode) { return carve_train(nullptr, n, n_conv, mode).total; }
 
 static int train_opt_in() {
     static std::mutex mu;
@@ -676,13 +676,16 @@ int train_bit_images(const void* workspace, int64_t n, int n_conv, uint8_t* mask
     return WW_OK;
 }
 
-int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, void* workspace,
-                  float* logits, hipStream_t st) {
+int train_forward(const float* mel, int64_t n, int width, const ww_train_params* p, float p_lstm, float p_fc, uint64_t seed, int mode,
+                  void* workspace, int64_t workspace_bytes, float* logits, hipStream_t st) {
     if (device_cu_count() > kMaxGroups) return fail(WW_EUNSUPPORTED, "more than 256 CUs: the workspace is sized for 256 partials");
     const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
-    TrainWs w = carve_train(workspace, n, nc);
-    note_workspace_mode(workspace, train_math_mode());
-    if (train_math_mode() == WW_TRAIN_MATH_F16X3) {
+    TrainWs w = carve_train(workspace, n, nc, mode);
+    if (workspace_bytes < w.total)
+        return fail(WW_EINVAL, "training workspace of %lld bytes, but %lld clips of the %d-conv model under train math %d need %lld "
+                               "(ww_train_workspace_bytes with the same mode)", (long long)workspace_bytes, (long long)n, nc, mode, (long long)w.total);
+    note_workspace_mode(workspace, mode);
+    if (mode == WW_TRAIN_MATH_F16X3) {
         // split precision: the inference kernels (convs as 1-D Winograd on the f16 matrix cores) with the ReLU masks as extra outputs.
         // 2 convs: relu(conv2) itself is never stored.  3 convs: relu(conv2) stays as float32 [row][column][64].
         // The backward pass must run under the same arithmetic (it reads the bit images).
@@ -721,18 +724,21 @@ static int reduce_to(const TrainWs& w, int groups, int len, int w_len, float* dw
     return WW_OK;
 }
 
-int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, void* workspace,
-                   const ww_train_grads* g, hipStream_t st) {
+int train_backward(const float* mel, int64_t n, int width, const ww_train_params* p, const float* dlogits, int mode, void* workspace,
+                   int64_t workspace_bytes, const ww_train_grads* g, hipStream_t st) {
     if (int rc = train_opt_in()) return rc;
     const int nc = p->n_conv, c_last = nc == 3 ? 128 : 64;
     const int cus = device_cu_count();
     const int grid = int(n < cus ? n : cus);         // one persistent workgroup per CU (117-149 KB of LDS each)
-    if (const int fwd = workspace_mode(workspace); fwd >= 0 && fwd != train_math_mode())
-        return fail(WW_EINVAL, "the forward of this workspace ran under train math %d, the backward is asked under %d: set the same mode "
-                               "(ww_set_train_math) for both halves of a step", fwd, train_math_mode());
-    TrainWs w = carve_train(workspace, n, nc);
+    if (const int fwd = workspace_mode(workspace); fwd >= 0 && fwd != mode)
+        return fail(WW_EINVAL, "the forward of this workspace ran under train math %d, the backward is asked under %d: pass the same mode "
+                               "to both halves of a step", fwd, mode);
+    TrainWs w = carve_train(workspace, n, nc, mode);
+    if (workspace_bytes < w.total)
+        return fail(WW_EINVAL, "training workspace of %lld bytes, but %lld clips of the %d-conv model under train math %d need %lld",
+                    (long long)workspace_bytes, (long long)n, nc, mode, (long long)w.total);
     const int N = int(n), H = kHidden;
-    const bool bits = train_math_mode() == WW_TRAIN_MATH_F16X3;       // the forward left bit images (and channels-last relu(conv2))
+    const bool bits = mode == WW_TRAIN_MATH_F16X3;       // the forward left bit images (and channels-last relu(conv2))
     const bool split = bits && nc == 2;                               // the kernels of ww_train_h.hip
     // fc: dW = dlogits^T hd1, db = the row sums of dlogits^T, dhd1 = dlogits W_fc
     sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st, g->fc_bias);

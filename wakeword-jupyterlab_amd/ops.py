@@ -258,7 +258,12 @@ def _train_params_struct(params, n_conv):
 class _TrainStep(torch.autograd.Function):
     """logits = model(x) in train mode, with d loss / d parameters from the HIP backward kernels.  `x` gets no gradient (the
     reference never asks for one)."""
-    last_workspace = None
+    # diagnostics only (train_last_masks / _packed_image / _bit_images): a WEAK reference to the newest step's workspace, so that it
+    # does not outlive its step (a strong one kept 2.7 GB alive behind every fp32 step); tests that read it after the backward
+    # switch keep_train_workspace(True) on
+    _last_ws_ref = None
+    _last_ws_keep = None
+    keep = False
     last_n_conv = 2
     last_n = 0
 
@@ -272,15 +277,18 @@ class _TrainStep(torch.autograd.Function):
         if B == 0:
             raise ValueError("empty training batch")
         logits = torch.empty((B, 2), device=x.device, dtype=torch.float32)
+        math = nat.lib.ww_get_train_math()                  # resolved ONCE: query, forward and backward of this step all get this value
         with torch.cuda.device(x.device):
-            ws = torch.empty(nat.check(nat.lib.ww_train_workspace_bytes(B, n_conv)), device=x.device, dtype=torch.uint8)
+            ws = torch.empty(nat.check(nat.lib.ww_train_workspace_bytes(B, n_conv, math)), device=x.device, dtype=torch.uint8)
             tp = _train_params_struct(params, n_conv)
             nat.check(nat.lib.ww_train_forward_f32(_ptr(x), B, T, C.byref(tp), float(p_lstm), float(p_fc), int(seed) & (2 ** 64 - 1),
-                                                   _ptr(ws), _ptr(logits), _stream()))
+                                                   math, _ptr(ws), ws.numel(), _ptr(logits), _stream()))
         ctx.save_for_backward(x, ws, *params)
         ctx.n_conv = n_conv
-        ctx.train_math = nat.lib.ww_get_train_math()        # the backward reads what this forward left in the workspace
-        _TrainStep.last_workspace, _TrainStep.last_n_conv, _TrainStep.last_n = ws, n_conv, B
+        ctx.train_math = math
+        import weakref
+        _TrainStep._last_ws_ref, _TrainStep.last_n_conv, _TrainStep.last_n = weakref.ref(ws), n_conv, B
+        _TrainStep._last_ws_keep = ws if _TrainStep.keep else None
         return logits
 
     @staticmethod
@@ -301,12 +309,8 @@ class _TrainStep(torch.autograd.Function):
         tg.fc_weight, tg.fc_bias = grads[o + 8].data_ptr(), grads[o + 9].data_ptr()
         with torch.cuda.device(x.device):
             tp = _train_params_struct(params, n_conv)
-            now = nat.lib.ww_get_train_math()
-            nat.check(nat.lib.ww_set_train_math(ctx.train_math))
-            try:
-                nat.check(nat.lib.ww_train_backward_f32(_ptr(x), B, T, C.byref(tp), _ptr(dlogits), _ptr(ws), C.byref(tg), _stream()))
-            finally:
-                nat.check(nat.lib.ww_set_train_math(now))
+            nat.check(nat.lib.ww_train_backward_f32(_ptr(x), B, T, C.byref(tp), _ptr(dlogits), ctx.train_math, _ptr(ws), ws.numel(),
+                                                    C.byref(tg), _stream()))
         grads[o + 3].copy_(grads[o + 2])    # d/d bias_hh == d/d bias_ih
         grads[o + 7].copy_(grads[o + 6])
         return (None, None, None, None, None, *grads)
@@ -317,9 +321,24 @@ def train_forward(x, named_params: dict, n_conv: int, p_lstm: float, p_fc: float
     return _TrainStep.apply(x, n_conv, p_lstm, p_fc, seed, *[named_params[k] for k in _train_keys(n_conv)])
 
 
+def keep_train_workspace(on: bool = True) -> None:
+    """Diagnostics switch: hold a strong reference to the newest training step's workspace so that train_last_* can read it after
+    the step's autograd graph is gone (off by default: the workspace then dies with its step)."""
+    _TrainStep.keep = bool(on)
+    if not on:
+        _TrainStep._last_ws_keep = None
+
+
+def _last_workspace() -> torch.Tensor:
+    ws = _TrainStep._last_ws_ref() if _TrainStep._last_ws_ref is not None else None
+    if ws is None:
+        raise RuntimeError("no live training workspace: the last step's graph was freed (ops.keep_train_workspace(True) keeps it for diagnostics)")
+    return ws
+
+
 def train_last_masks(n: int):
     """Dropout factors of the most recent training forward: (mask0 [n,256], mask1 [n,256]) -- tests replay them elsewhere."""
-    ws = _TrainStep.last_workspace
+    ws = _last_workspace()
     m0 = torch.empty((n, 256), device=ws.device, dtype=torch.float32)
     m1 = torch.empty_like(m0)
     with torch.cuda.device(ws.device):
@@ -329,7 +348,7 @@ def train_last_masks(n: int):
 
 def train_last_packed_image() -> torch.Tensor:
     """Diagnostic: the packed image the most recent split-precision training forward of the 2-conv model wrote on the device."""
-    ws = _TrainStep.last_workspace
+    ws = _last_workspace()
     img = torch.empty(int(nat.lib.ww_packed_weights_floats(_TrainStep.last_n_conv)), device=ws.device, dtype=torch.float32)
     with torch.cuda.device(ws.device):
         nat.check(nat.lib.ww_train_packed_image(_ptr(ws), _TrainStep.last_n, _TrainStep.last_n_conv, _ptr(img), _stream()))
@@ -338,7 +357,7 @@ def train_last_packed_image() -> torch.Tensor:
 
 def train_last_bit_images():
     """Diagnostic: (mask_last uint8 [n,80,32,C/8], sign1 int32 [n,80,32]) of the most recent split-precision training forward."""
-    ws, n, nc = _TrainStep.last_workspace, _TrainStep.last_n, _TrainStep.last_n_conv
+    ws, n, nc = _last_workspace(), _TrainStep.last_n, _TrainStep.last_n_conv
     mask = torch.empty((n, 80, 32, 8 if nc == 2 else 16), device=ws.device, dtype=torch.uint8)
     sign1 = torch.empty((n, 80, 32), device=ws.device, dtype=torch.int32)
     with torch.cuda.device(ws.device):
