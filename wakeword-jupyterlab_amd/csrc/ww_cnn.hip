@@ -49,6 +49,15 @@ __device__ __forceinline__ void zero_lds(float* p, int n, int tid, int nthreads)
     for (int i = tid; i < n; i += nthreads) p[i] = 0.f;
 }
 
+// Pooling order (all conv kernels): the values of one tile step are summed as a balanced tree and the step's partial is then added to
+// the running total -- the same number of adds as one long chain, but the chain is 10-40 partials long instead of 640-1280 values.
+// A long chain of near-equal addends (a constant image: every position the same activation) rounds the same way at every step and
+// drifted the pooled mean by 1.6e-5 relative in the exact-fp32 kernels (tests/test_gpu_guards.py, w:scaled_1e-6); partial sums of equal
+// values are exact doublings.
+__device__ __forceinline__ float tree4(float a, float b, float c, float d) { return (a + b) + (c + d); }
+__device__ __forceinline__ float tree8(const float* v) { return tree4(v[0], v[1], v[2], v[3]) + tree4(v[4], v[5], v[6], v[7]); }
+__device__ __forceinline__ float tree16(const float* v) { return tree8(v) + tree8(v + 8); }
+
 // conv1 for one band: act[ci][q][x+1] = relu(b1[ci] + sum w1[ci][dy][dx] * mel[y+dy-1][x+dx-1]),
 // y = y0 - 1 + q; zero where the position lies outside the image (that is conv2's zero padding).
 // wave w computes channels 8w..8w+7 (wave-uniform -> scalar weight loads); lane = (column, row parity).
@@ -149,14 +158,19 @@ __global__ __launch_bounds__(256, 2) void cnn2_kernel(const float* __restrict__ 
             mfma_rows4<kARows>(ap, wb, acc);
             // D layout: lane&31 = channel, register j <-> column (j&3) + 8*(j>>2) + 4*(lane>>5)
             if constexpr (POOL) {
+                float rows[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    float vs[16];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
                         const float v = relu(acc[r][j] + bias);
-                        pool += (col < width) ? v : 0.f;
+                        vs[j] = (col < width) ? v : 0.f;
                     }
+                    rows[r] = tree16(vs);
+                }
+                pool += tree4(rows[0], rows[1], rows[2], rows[3]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -569,18 +583,22 @@ __global__ __launch_bounds__(768, 3) void cnn2h16_kernel(const float* __restrict
                             o16[rec + 64] = static_cast<_Float16>(v - static_cast<float>(hi));
                         }
                 } else if (width == kW) {
+                    float vs[8];
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) pool += relu2(fmaf(acc[r][c][j], dsc, bias));
+                        for (int j = 0; j < 4; ++j) vs[4 * c + j] = relu2(fmaf(acc[r][c][j], dsc, bias));
+                    pool += tree8(vs);
                 } else {
+                    float vs[8];
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float v = relu2(fmaf(acc[r][c][j], dsc, bias));
-                            pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
+                            vs[4 * c + j] = (16 * c + 4 * kq + j < width) ? v : 0.f;
                         }
+                    pool += tree8(vs);
                 }
             };
             // fragments run TWO steps ahead of their MFMAs in a 3-deep register ring; the scheduling barriers keep the
@@ -937,6 +955,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             flag_signal(&free_cnt[b]);                       // the buffer is free as soon as its fragments are in the accumulators
             // output transform + bias + 2*relu + pool (D: lane & 15 = channel, register j <-> column 16 c + 4 kq + j)
             const int trow = kWPerProd * (2 * grp + (sq & 1)) + (sq >> 1);      // the tile row this step holds (producer 2 grp + (sq & 1), its i-th)
+            float pv[8];                                        // the tile row's eight (v0 + v1) pairs: summed as a tree, then into `pool`
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 unsigned long long live0[4], live1[4];
@@ -947,7 +966,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                     const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
                     const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
                     if constexpr (POOL) {
-                        pool += col_live ? v0 + v1 : 0.f;
+                        pv[4 * c + j] = col_live ? v0 + v1 : 0.f;
                     } else {
                         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
                         float* o = out + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + j) * 64 + 16 * nt + pi;
@@ -975,6 +994,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                     }
                 }
             }
+            if constexpr (POOL) pool += tree8(pv);
             if (POOL && sq == kWPerGroup - 1) {               // this wave's last tile row of the clip
                 float p2 = pool + __shfl_xor(pool, 16);
                 p2 += __shfl_xor(p2, 32);
@@ -1081,12 +1101,13 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
 
     if (steps > 0) { fetch(0); stash(0); }
     __syncthreads();
-    float pool = 0.f, dsc = descale;
+    float pool = 0.f, pool4 = 0.f, dsc = descale;     // pool4: partial over four tile rows (pooling order: see tree4 above)
     for (int g = 0; g < steps; ++g) {
         const int k = g / kWTileRows, t = g - k * kWTileRows;
         if (t == 0) {
             dsc = descale * apow2[int64_t(blockIdx.x) + int64_t(k) * gridDim.x];    // the tile holds V * 2^-a2
             pool = 0.f;
+            pool4 = 0.f;
         }
         if (g + 1 < steps) fetch(g + 1);
         const char* ap = ldsb + (g & 1) * kW3Buf + pi * kW3Rec + kq * 16;
@@ -1117,18 +1138,21 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
             }
             unsigned long long live0[4], live1[4];
+            float pv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float m12 = acc[1][j] + acc[2][j], m1m2 = acc[1][j] - acc[2][j];
                 const float y0 = acc[0][j] + m12, y1 = m1m2 - acc[3][j];
                 const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
                 const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
-                pool += col_live ? v0 + v1 : 0.f;
+                pv[j] = col_live ? v0 + v1 : 0.f;
                 if constexpr (BITS) {           // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
                     live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
                     live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
                 }
             }
+            if constexpr (BITS) pool += tree4(pv[0], pv[1], pv[2], pv[3]);     // training forward: at its 256-VGPR cap a second accumulator costs 6 spills
+            else pool4 += tree4(pv[0], pv[1], pv[2], pv[3]);
             if constexpr (BITS) {
                 // the eight ballots of (row r, register j) go out as they are: 64 contiguous bytes per (tile row, N-tile, column half) =
                 // [r][j] x 64 bits, bit 16 kq + pi <-> column 16 c + 4 kq + j, channel 16 nt + pi.  v_writelane moves each half into
@@ -1151,6 +1175,7 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
             // landed by now, and this wave's transform + stores run under its SIMD sibling's MFMAs instead of in front of the barrier
             if (c == 0 && g + 1 < steps) stash(g + 1);
         }
+        if (!BITS && (t & 3) == 3) { pool += pool4; pool4 = 0.f; }      // kWTileRows = 40: the last partial is folded in before the reduction
         if (t == kWTileRows - 1) {
             float p2 = pool + __shfl_xor(pool, 16);
             p2 += __shfl_xor(p2, 32);
@@ -1225,6 +1250,7 @@ __global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ 
             }
             __syncthreads();
             if (kh == 0) {
+                float rows[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float vs[16];
@@ -1233,8 +1259,8 @@ __global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ 
                         const int col = (j & 3) + 8 * (j >> 2) + 4 * h;
                         const float v = relu(acc[r][j] + xch[((nt * 4 + r) * 16 + j) * 64 + lane] + bias);
                         vs[j] = (col < width) ? v : 0.f;
-                        pool += vs[j];
                     }
+                    rows[r] = tree16(vs);
                     if constexpr (STORE) {
                         float* dst = mid3 + ((int64_t(clip) * kH + y0 + r) * 128 + 32 * nt + x) * kW + 4 * h;
 #pragma unroll
@@ -1242,6 +1268,7 @@ __global__ __launch_bounds__(512, 2) void cnn3_kernel(const float* __restrict__ 
                             *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(vs[4 * g], vs[4 * g + 1], vs[4 * g + 2], vs[4 * g + 3]);
                     }
                 }
+                pool += tree4(rows[0], rows[1], rows[2], rows[3]);
             }
         }
         if (kh == 0) {
@@ -1349,15 +1376,22 @@ __global__ __launch_bounds__(512, 2) void cnn3h_kernel(const _Float16* __restric
             __builtin_amdgcn_sched_barrier(0);
         }
         if (band == 0) pool = 0.f;
+        {
+            float rows[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
+                float vs[8];
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = relu2(fmaf(acc[r][c][j], dsc, bias));
-                    pool += (16 * c + 4 * kq + j < width) ? v : 0.f;
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = relu2(fmaf(acc[r][c][j], dsc, bias));
+                        vs[4 * c + j] = (16 * c + 4 * kq + j < width) ? v : 0.f;
+                    }
+                rows[r] = tree8(vs);
+            }
+            pool += tree4(rows[0], rows[1], rows[2], rows[3]);
+        }
         if (band == bands - 1) {
             float p2 = pool + __shfl_xor(pool, 16);
             p2 += __shfl_xor(p2, 32);

@@ -49,7 +49,8 @@ struct K1Layout {
     static constexpr int kOffFrm = kOffRed + 16;            // auto mode: [WAVES][32] per-frame energy partials, [80] 1 / wmax_b, [4] redo flag
     static constexpr int kOffInvw = kOffFrm + WAVES * 32;
     static constexpr int kOffFlag = kOffInvw + kMels;
-    static constexpr int kOffPinfo = kOffFlag + 4;          // [kPieces] ints
+    static constexpr int kOffDcNy = kOffFlag + 4;           // auto mode: [32] |X_0|^2 + |X_1024|^2 per frame (the two bins no mel band sees)
+    static constexpr int kOffPinfo = kOffDcNy + 32;         // [kPieces] ints
     static constexpr int kOffFp0 = kOffPinfo + kPieces;     // [80] ints
     static constexpr int kOffFcnt = kOffFp0 + kMels;        // [80] ints
     static constexpr int kOffTw2 = kOffFcnt + kMels;        // [7][16] float2
@@ -158,7 +159,8 @@ constexpr uint32_t kRedoMark = 0x7fc5a11eu;
 // E = sum_k |X_k|^2; a band's power P_b = sum_k M_bk |X_k|^2 then carries a relative error of ~2 sigma sqrt(wmax_b / P_b),
 // which exceeds 1e-4 dB below P_b / wmax_b ~ 4e-6 E (measured on MI355X: scripts/diag_floor.py).  A frame with a live band
 // below kFloorRatio * E sends its clip to the float64 kernel.  E is estimated from the mel tile itself: the triangles
-// M_bk / wmax_b are a partition of unity over the bins, so sum_b P_b / wmax_b ~ E.
+// M_bk / wmax_b are a partition of unity over the bins 1..1023, so sum_b P_b / wmax_b ~ E without the DC and Nyquist bins, which carry
+// zero mel weight; those two are added from Z[0] (round 3: a pure Nyquist tone was missed without them, 1.07e-4 dB).
 #ifndef WW_FLOOR_RATIO
 #define WW_FLOOR_RATIO 1.0e-5f
 #endif
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
     using L = K1Layout<WAVES>;
     constexpr int kWavesPerBlock = WAVES, kThreads = L::kThreads;
     constexpr int kOffMel = L::kOffMel, kOffRed = L::kOffRed, kOffFrm = L::kOffFrm, kOffInvw = L::kOffInvw, kOffFlag = L::kOffFlag,
-                  kOffPinfo = L::kOffPinfo, kOffFp0 = L::kOffFp0,
+                  kOffDcNy = L::kOffDcNy, kOffPinfo = L::kOffPinfo, kOffFp0 = L::kOffFp0,
                   kOffFcnt = L::kOffFcnt, kOffTw2 = L::kOffTw2, kOffTwp = L::kOffTwp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* mel = lds + kOffMel;                                 // [80][33]
@@ -416,7 +418,14 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
                     a[j] = za_p[64 * j];
                     b[j] = zb_p[64 * (15 - j)];
                 }
-                if (lane == 0) { a[0] = slab2[512]; b[0] = a[0]; }
+                if (lane == 0) {
+                    // lane 0's first read is Z[0] = (sum of even samples, sum of odd samples): X_0 = Zr + Zi, X_1024 = Zr - Zi.  No mel band
+                    // sees these two bins, but their energy feeds the float FFT's rounding floor like any other bin's: auto mode's
+                    // frame-energy estimate needs it (a Nyquist- or DC-dominated frame otherwise looks 60 dB quieter than it is)
+                    if (mark) lds[kOffDcNy + frame] = 2.0f * fmaf(a[0].x, a[0].x, a[0].y * a[0].y);   // (Zr+Zi)^2 + (Zr-Zi)^2
+                    a[0] = slab2[512];
+                    b[0] = a[0];
+                }
                 float2 twj[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) twj[j] = twp_2[lane + 64 * j];
@@ -532,6 +541,7 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
         if (mark) {
 #pragma unroll
             for (int w = 0; w < kWavesPerBlock; ++w) floor_e += frm[w * 32 + (tid & 31)];
+            floor_e += lds[kOffDcNy + (tid & 31)];
             floor_e *= kFloorRatio;
         }
         const float live_thr = fmaxf(mmax * 0.99e-8f, amin / g2);
