@@ -10,7 +10,7 @@ obj=build/var_$name
 mkdir -p $obj build/ab
 flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I. -Wall -Wno-unused-function -fvisibility=hidden -DWW_BUILD -fno-slp-vectorize"
 pids=()
-for src in ww_tables.cpp ww_logmel.hip ww_cnn.hip ww_head.hip ww_decode.hip ww_augment.hip ww_train.hip ww_train_h.hip ww_api.hip; do
+for src in ww_tables.cpp ww_logmel.hip ww_cnn.hip ww_head.hip ww_decode.hip ww_files.cpp ww_augment.hip ww_train.hip ww_train_h.hip ww_api.hip; do
   /opt/rocm/bin/hipcc $flags "$@" -x hip -c $src -o $obj/${src%.*}.o &
   pids+=($!)
 done

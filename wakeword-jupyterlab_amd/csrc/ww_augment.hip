@@ -10,7 +10,8 @@
 //                     packed real frame (ww_fft.h), real-input split -> D[frame][0..1024] complex64
 //   pv_kernel         phase vocoder: thread = bin, sequential over the output steps; librosa's arithmetic types are
 //                     kept (float32 magnitudes and phase accumulator, float64 phase advance) so that the accumulator
-//                     rounds the same way
+//                     rounds the same way; angle / magnitude / phasor by short in-kernel forms (round 3) instead of libm's
+//                     atan2f / hypotf / sincosf
 //   istft_kernel      Hermitian spectrum -> conj(Z) -> the same forward FFT -> frame, four frames per round into a ring
 //                     of eight LDS slabs; the hop segments a round completes are summed straight from the slabs in
 //                     frame order with the window and its sum-square, centre-trimmed, cropped / zero-padded
@@ -101,6 +102,39 @@ __device__ __forceinline__ float2 pv_col(const float2* __restrict__ Dc, int f, i
     return f < kAugFrames ? Dc[int64_t(f) * kSpec + k] : make_float2(0.f, 0.f);     // librosa pads two zero columns
 }
 
+// atan2 for the vocoder: a = min/max in [0, 1], atan(a) = a P(a^2) (degree 8 in a^2, |err| <= 1.2e-7 in float32 evaluation -- the size of
+// libm's own last-place error at these magnitudes), octant and quadrant folded back; signed zeros and (0, 0) as atan2f has them.
+__device__ __forceinline__ float pv_atan2(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.f ? mn / mx : 0.f;
+    const float q = a * a;
+    float p = 2.399661113e-03f;
+    p = fmaf(p, q, -1.415910292e-02f);
+    p = fmaf(p, q, 3.935785964e-02f);
+    p = fmaf(p, q, -7.195615768e-02f);
+    p = fmaf(p, q, 1.047824398e-01f);
+    p = fmaf(p, q, -1.415504068e-01f);
+    p = fmaf(p, q, 1.998492777e-01f);
+    p = fmaf(p, q, -3.333252668e-01f);
+    p = fmaf(p, q, 9.999998808e-01f);
+    float r = a * p;
+    r = ay > ax ? 1.57079632679489662f - r : r;
+    r = __builtin_signbitf(x) ? 3.14159265358979324f - r : r;
+    return __builtin_copysignf(r, y);
+}
+
+// cos / sin of the float32 phase accumulator.  The accumulator reaches 10^4 .. 10^5 radians (phi = pi k / 2 per step): libm's sincosf takes
+// its large-argument reduction path there (round 2: the bulk of this kernel's time).  Here the turn count acc / 2 pi is formed in double, its
+// fraction goes to the hardware's v_sin_f32 / v_cos_f32 (arguments in revolutions; absolute error ~1e-6, five hundred times under the tests' bound
+// on the output samples).
+__device__ __forceinline__ void pv_sincos(float acc, float& sn, float& cs) {
+    const double turns = double(acc) * 0.15915494309189533576888;       // 1 / (2 pi)
+    const float fr = float(turns - __builtin_rint(turns));                // [-0.5, 0.5]
+    sn = __builtin_amdgcn_sinf(fr);
+    cs = __builtin_amdgcn_cosf(fr);
+}
+
 __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, const AugDev* __restrict__ plan, int which,
                                                  float2* __restrict__ S) {
 #pragma clang fp contract(off)
@@ -114,7 +148,7 @@ __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, c
     for (int k = threadIdx.x; k < kSpec; k += 256) {
         const double phi = double(k) * two_pi * 0.25;            // hop * 2 pi k / n_fft
         const float2 d0 = Dc[k];
-        float acc = atan2f(d0.y, d0.x);                          // np.angle(D[:, 0]): float32 accumulator
+        float acc = pv_atan2(d0.y, d0.x);                        // np.angle(D[:, 0]): float32 accumulator
         // |c| and angle(c) of the two columns a step reads are kept from the previous step: the column index moves on by 0, 1 or 2 per
         // step (uniform over the workgroup), so most steps compute one new column instead of two (same values, a third less work)
         int have = -2;                                           // columns `have`, `have + 1` are in (m0, a0), (m1, a1)
@@ -125,15 +159,15 @@ __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, c
             const double alpha = step - double(i0);
             if (i0 != have) {
                 if (i0 == have + 1) { m0 = m1; a0 = a1; }
-                else { const float2 c0 = pv_col(Dc, i0, k); m0 = hypotf(c0.x, c0.y); a0 = atan2f(c0.y, c0.x); }
+                else { const float2 c0 = pv_col(Dc, i0, k); m0 = sqrtf(fmaf(c0.x, c0.x, c0.y * c0.y)); a0 = pv_atan2(c0.y, c0.x); }
                 const float2 c1 = pv_col(Dc, i0 + 1, k);
-                m1 = hypotf(c1.x, c1.y);
-                a1 = atan2f(c1.y, c1.x);
+                m1 = sqrtf(fmaf(c1.x, c1.x, c1.y * c1.y));       // |c|: STFT magnitudes of unit-peak clips stay far inside float range
+                a1 = pv_atan2(c1.y, c1.x);
                 have = i0;
             }
             const float mag = float(1.0 - alpha) * m0 + float(alpha) * m1;
             float sn, cs;
-            sincosf(acc, &sn, &cs);
+            pv_sincos(acc, sn, cs);
             Sc[int64_t(t) * kSpec + k] = make_float2(cs * mag, sn * mag);
             const float da = a1 - a0;
             double dphase = double(da) - phi;
@@ -293,24 +327,34 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
+// Four samples per thread (float4 in, float4 out).  The uniforms are the hash generator's exact 32-bit words; Box-Muller runs in float32
+// (round 2: float64 log / sqrt / cos, 0.35 ms per 4096 clips for a 0.5 GB stream; the float32 form is bound by that stream).  Against the
+// float64 evaluation the normal deviate moves by <= 3e-7 of sigma, four orders under the augmentation tests' tolerance.
 __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ in, const AugDev* __restrict__ plan,
                                                     float* __restrict__ out, int64_t out_stride) {
     const int clip = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = 4 * (blockIdx.x * 256 + threadIdx.x);
     if (i >= kClip) return;
-    float v = in[int64_t(clip) * kClip + i];
+    float4 v = *reinterpret_cast<const float4*>(in + int64_t(clip) * kClip + i);
     const float sigma = plan[clip].sigma;
     if (sigma != 0.f) {
         const uint64_t seed = plan[clip].seed;
         const uint64_t k1 = mix64(seed * 0x9E3779B97F4A7C15ull + 1ull * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
         const uint64_t k2 = mix64(seed * 0x9E3779B97F4A7C15ull + 2ull * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
-        const uint64_t j = uint64_t(i) + 1ull;
-        const double u1 = (double(uint32_t(mix64(k1 + j * 0x9E3779B97F4A7C15ull) >> 32)) + 0.5) * (1.0 / 4294967296.0);
-        const double u2 = (double(uint32_t(mix64(k2 + j * 0x9E3779B97F4A7C15ull) >> 32)) + 0.5) * (1.0 / 4294967296.0);
-        const double nrm = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
-        v = float(double(v) + double(sigma) * nrm);
+        float* pv = &v.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t j = uint64_t(i + q) + 1ull;
+            const uint32_t w1 = uint32_t(mix64(k1 + j * 0x9E3779B97F4A7C15ull) >> 32), w2 = uint32_t(mix64(k2 + j * 0x9E3779B97F4A7C15ull) >> 32);
+            const float u1 = (float(w1 >> 8) + 0.5f + float(w1 & 0xffu) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);   // (w1 + 0.5) / 2^32 to float32
+            const float u2 = (float(w2 >> 8) + float(w2 & 0xffu) * (1.0f / 256.0f)) * (1.0f / 16777216.0f) + (0.5f / 4294967296.0f);
+            const float nrm = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+            pv[q] = fmaf(sigma, nrm, pv[q]);
+        }
     }
-    out[int64_t(clip) * out_stride + i] = v;
+    float* o = out + int64_t(clip) * out_stride + i;
+    if ((out_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) *reinterpret_cast<float4*>(o) = v;
+    else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,7 +468,7 @@ int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const vo
         hipLaunchKernelGGL(istft_kernel, dim3(unsigned(n)), dim3(256), kIstftLds, stream, S, plan, 1, tb, cur, other, int64_t(kClip));
         float* t = cur; cur = other; other = t;
     }
-    hipLaunchKernelGGL(noise_kernel, egrid, dim3(256), 0, stream, cur, plan, out, out_stride);
+    hipLaunchKernelGGL(noise_kernel, dim3((kClip / 4 + 255) / 256, unsigned(n)), dim3(256), 0, stream, cur, plan, out, out_stride);
     WW_HIP(hipGetLastError());
     return WW_OK;
 }

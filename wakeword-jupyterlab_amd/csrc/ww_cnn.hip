@@ -23,6 +23,7 @@
 // Algorithmic flops per clip (T = 32): conv1 1,474,560 + conv2 94,371,840 [+ conv3 377,487,360].
 // Diagnostic build: -DWW_STAMPS adds s_memtime phase stamps (never in the shipped library).
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 
 #include "ww_conv1.h"
@@ -747,7 +748,6 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
 
     const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
     const int steps = my_clips * kWTileRows;
-    const float half_inv_area = 0.5f / float(kH * width);
 
     if (!consumer) {
         // ================================================= producers =================================================
@@ -956,44 +956,50 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             // output transform + bias + 2*relu + pool (D: lane & 15 = channel, register j <-> column 16 c + 4 kq + j)
             const int trow = kWPerProd * (2 * grp + (sq & 1)) + (sq >> 1);      // the tile row this step holds (producer 2 grp + (sq & 1), its i-th)
             float pv[8];                                        // the tile row's eight (v0 + v1) pairs: summed as a tree, then into `pool`
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                unsigned long long live0[4], live1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float m12 = acc[1][c][j] + acc[2][c][j], m1m2 = acc[1][c][j] - acc[2][c][j];
-                    const float y0 = acc[0][c][j] + m12, y1 = m1m2 - acc[3][c][j];
-                    const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
-                    const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
-                    if constexpr (POOL) {
-                        pv[4 * c + j] = col_live ? v0 + v1 : 0.f;
-                    } else {
-                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                        float* o = out + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + j) * 64 + 16 * nt + pi;
-                        o[0] = col_live ? 0.5f * v0 : 0.f;
-                        o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
+            // width == 32 (every clip of the mel path) runs a copy of the epilogue without the eight column selects
+            auto epilogue = [&](auto fullw) {
+                constexpr bool FULLW = decltype(fullw)::value;
+    #pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    unsigned long long live0[4], live1[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float m12 = acc[1][c][j] + acc[2][c][j], m1m2 = acc[1][c][j] - acc[2][c][j];
+                        const float y0 = acc[0][c][j] + m12, y1 = m1m2 - acc[3][c][j];
+                        const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
+                        const bool col_live = FULLW || 16 * c + 4 * kq + j < width;
+                        if constexpr (POOL) {
+                            pv[4 * c + j] = col_live ? v0 + v1 : 0.f;
+                        } else {
+                            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                            float* o = out + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + j) * 64 + 16 * nt + pi;
+                            o[0] = col_live ? 0.5f * v0 : 0.f;
+                            o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
+                        }
+                        if constexpr (BITS) {       // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
+                            live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
+                            live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
+                        }
                     }
-                    if constexpr (BITS) {       // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
-                        live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
-                        live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
+                    if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
+                        uint32_t word = 0u;
+                        word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
+                        word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
+                        word = write_lane<4>(uint32_t(live0[2]), word);  word = write_lane<5>(uint32_t(live0[2] >> 32), word);
+                        word = write_lane<6>(uint32_t(live0[3]), word);  word = write_lane<7>(uint32_t(live0[3] >> 32), word);
+                        word = write_lane<8>(uint32_t(live1[0]), word);  word = write_lane<9>(uint32_t(live1[0] >> 32), word);
+                        word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
+                        word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
+                        word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
+                        if (lane < 16) {
+                            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                            reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16) + lane] = word;
+                        }
                     }
                 }
-                if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
-                    uint32_t word = 0u;
-                    word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
-                    word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
-                    word = write_lane<4>(uint32_t(live0[2]), word);  word = write_lane<5>(uint32_t(live0[2] >> 32), word);
-                    word = write_lane<6>(uint32_t(live0[3]), word);  word = write_lane<7>(uint32_t(live0[3] >> 32), word);
-                    word = write_lane<8>(uint32_t(live1[0]), word);  word = write_lane<9>(uint32_t(live1[0] >> 32), word);
-                    word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
-                    word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
-                    word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
-                    if (lane < 16) {
-                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                        reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16) + lane] = word;
-                    }
-                }
-            }
+            };
+            if (width == kW) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
             if constexpr (POOL) pool += tree8(pv);
             if (POOL && sq == kWPerGroup - 1) {               // this wave's last tile row of the clip
                 float p2 = pool + __shfl_xor(pool, 16);
@@ -1008,8 +1014,11 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                 if (old + 1u == 8u * unsigned(k / 2 + 1)) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                    const int t_nt = lane >> 4, t_n = lane & 15;
-                    out[clip * 64 + lane] = (rk[t_nt * 16 + t_n] + rk[(4 + t_nt) * 16 + t_n]) * half_inv_area;
+                    // once per clip: the lane index and the scale are RECOMPUTED here (mbcnt; a scalar divide) instead of being kept in
+                    // VGPRs across the MFMA loop, where at the 168-register cap they were spilled to scratch
+                    const int ln = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+                    const float scale = 0.5f / float(kH * __builtin_amdgcn_readfirstlane(width));
+                    out[clip * 64 + ln] = (rk[ln] + rk[64 + ln]) * scale;
                 }
             }
         }

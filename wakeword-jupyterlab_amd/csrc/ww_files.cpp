@@ -47,12 +47,10 @@ static bool fetch(int fd, const uint8_t* win, int64_t win_len, int64_t pos, int6
 }
 
 // RIFF/WAVE chunk walk: the last `fmt ` and the last `data` chunk win, odd chunk sizes are padded, a data chunk longer
-// than the file is cut at the end of the file (the host reader of audio.py walks the same way).
-static int parse_wav(int fd, int64_t fsize, WavInfo* w) {
-    uint8_t win[4096];
-    const int64_t win_len = fsize < int64_t(sizeof win) ? fsize : int64_t(sizeof win);
-    if (win_len < 12 || !fetch(fd, nullptr, 0, 0, win_len, win)) return WW_WAV_ENOTRIFF;
-    if (std::memcmp(win, "RIFF", 4) || std::memcmp(win + 8, "WAVE", 4)) return WW_WAV_ENOTRIFF;
+// than the file is cut at the end of the file (the host reader of audio.py walks the same way).  `win` holds the first
+// win_len bytes of the file; anything beyond is fetched with pread.
+static int parse_wav(int fd, int64_t fsize, const uint8_t* win, int64_t win_len, WavInfo* w) {
+    if (win_len < 12 || std::memcmp(win, "RIFF", 4) || std::memcmp(win + 8, "WAVE", 4)) return WW_WAV_ENOTRIFF;
     int64_t pos = 12;
     bool have_fmt = false;
     while (pos + 8 <= fsize) {
@@ -82,6 +80,32 @@ static int parse_wav(int fd, int64_t fsize, WavInfo* w) {
     return 1;
 }
 
+// The head of the file in ONE read: a 1 s / 16 kHz PCM-16 clip (32,044 bytes, the reference's data format) arrives whole, so a
+// file costs open + pread + close.  A read shorter than the window is the end of a regular file; the size is cross-checked
+// against the RIFF header's own and fstat decides when the two disagree or the window was filled.
+constexpr int64_t kHeadWindow = 68 * 1024;
+static int64_t read_head(int fd, uint8_t* win, int64_t* fsize_out) {
+    int64_t got = 0;
+    const ssize_t r = pread(fd, win, size_t(kHeadWindow), 0);
+    if (r < 0) return -1;
+    got = r;
+    int64_t fsize = got;
+    const bool riff_says_more = got >= 8 && !std::memcmp(win, "RIFF", 4) && int64_t(le32(win + 4)) + 8 > got;
+    if (got == kHeadWindow || riff_says_more) {
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
+        fsize = int64_t(sb.st_size);
+        while (got < kHeadWindow && got < fsize) {               // a short first read that was not the end of the file
+            const ssize_t r2 = pread(fd, win + got, size_t(kHeadWindow - got), off_t(got));
+            if (r2 <= 0) break;
+            got += r2;
+        }
+        if (fsize < got) fsize = got;
+    }
+    *fsize_out = fsize;
+    return got;
+}
+
 static int format_of(const WavInfo& w) {
     if (w.tag == 1 && w.bits == 16) return WW_FMT_S16;
     if (w.tag == 1 && w.bits == 24) return WW_FMT_S24;
@@ -106,7 +130,7 @@ struct Job {
     int64_t n = 0;
     Slot* slot = nullptr;
     int8_t* status = nullptr;
-    std::atomic<int64_t> next{0}, cursor{0}, need{0};
+    std::atomic<int64_t> next{0}, cursor{0};
     int64_t capacity = 0;
 };
 
@@ -133,17 +157,17 @@ struct ww_wav_reader {
 
 namespace ww {
 
-static void read_one(Job* j, int64_t i) {
+static void read_one(Job* j, int64_t i, uint8_t* win) {
     ww_clip_desc d;
     std::memset(&d, 0, sizeof d);
     d.channels = 1; d.format = WW_FMT_S16; d.up = 1; d.down = 1; d.sample_rate = WW_SAMPLE_RATE;   // what K0 sees for an unreadable file: nothing
     int st = WW_WAV_EOPEN;
     const int fd = j->paths[i] ? open(j->paths[i], O_RDONLY | O_CLOEXEC) : -1;
     if (fd >= 0) {
-        struct stat sb;
         WavInfo w;
-        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) st = WW_WAV_EIO;
-        else st = parse_wav(fd, int64_t(sb.st_size), &w);
+        int64_t fsize = 0;
+        const int64_t win_len = read_head(fd, win, &fsize);
+        st = win_len < 0 ? WW_WAV_EIO : parse_wav(fd, fsize, win, win_len, &w);
         if (st == 1) {
             const int fmt = format_of(w);
             if (!fmt || w.channels < 1 || w.sample_rate < 1000 || w.sample_rate > 384000) st = WW_WAV_EFORMAT;
@@ -151,12 +175,16 @@ static void read_one(Job* j, int64_t i) {
                 const int64_t frame_bytes = int64_t(w.channels) * (w.bits / 8);
                 const int64_t frames = w.data_len / frame_bytes, bytes = frames * frame_bytes;
                 const int64_t aligned = (bytes + 15) & ~int64_t(15);                          // every file starts 16-byte aligned
-                j->need.fetch_add(aligned, std::memory_order_relaxed);
                 const int64_t off = j->cursor.fetch_add(aligned, std::memory_order_relaxed);
                 if (off + aligned > j->capacity) st = WW_WAV_ESPACE;
                 else {
                     uint8_t* dst = j->slot->raw_host + off;
+                    // what the head window already holds is copied; the rest of a longer file is read straight into the staging buffer
                     int64_t got = 0;
+                    if (w.data_start < win_len) {
+                        got = win_len - w.data_start < bytes ? win_len - w.data_start : bytes;
+                        std::memcpy(dst, win + w.data_start, size_t(got));
+                    }
                     while (got < bytes) {
                         const ssize_t r = pread(fd, dst + got, size_t(bytes - got), off_t(w.data_start + got));
                         if (r <= 0) break;
@@ -176,6 +204,11 @@ static void read_one(Job* j, int64_t i) {
     j->status[i] = int8_t(st);
 }
 
+static void read_range(Job* j) {
+    std::vector<uint8_t> win(static_cast<size_t>(kHeadWindow), uint8_t(0));            // one window per participating thread and batch
+    for (int64_t i; (i = j->next.fetch_add(1, std::memory_order_relaxed)) < j->n;) read_one(j, i, win.data());
+}
+
 static void worker_main(ww_wav_reader* r) {
     uint64_t seen = 0;
     for (;;) {
@@ -187,7 +220,7 @@ static void worker_main(ww_wav_reader* r) {
             seen = r->generation;
             j = r->job;
         }
-        for (int64_t i; (i = j->next.fetch_add(1, std::memory_order_relaxed)) < j->n;) read_one(j, i);
+        read_range(j);
         {
             std::lock_guard<std::mutex> lk(r->mu);
             if (--r->active == 0) r->cv_done.notify_all();
@@ -197,7 +230,7 @@ static void worker_main(ww_wav_reader* r) {
 
 static void run_job(ww_wav_reader* r, Job* j) {
     if (r->workers.empty() || j->n < 4) {                     // tiny batches: not worth waking the pool
-        for (int64_t i = 0; i < j->n; ++i) read_one(j, i);
+        read_range(j);
         return;
     }
     {
@@ -207,7 +240,7 @@ static void run_job(ww_wav_reader* r, Job* j) {
         ++r->generation;
     }
     r->cv_work.notify_all();
-    for (int64_t i; (i = j->next.fetch_add(1, std::memory_order_relaxed)) < j->n;) read_one(j, i);   // the caller helps
+    read_range(j);                                             // the caller helps
     std::unique_lock<std::mutex> lk(r->mu);
     r->cv_done.wait(lk, [&] { return r->active == 0; });
     r->job = nullptr;
@@ -239,9 +272,11 @@ int ww_wav_probe_host(const char* path, ww_clip_desc* desc_host) {
     std::memset(desc_host, 0, sizeof *desc_host);
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return WW_WAV_EOPEN;
-    struct stat sb;
     WavInfo w;
-    int st = (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) ? WW_WAV_EIO : parse_wav(fd, int64_t(sb.st_size), &w);
+    std::vector<uint8_t> win(static_cast<size_t>(kHeadWindow), uint8_t(0));
+    int64_t fsize = 0;
+    const int64_t win_len = read_head(fd, win.data(), &fsize);
+    int st = win_len < 0 ? WW_WAV_EIO : parse_wav(fd, fsize, win.data(), win_len, &w);
     close(fd);
     if (st != 1) return st;
     const int fmt = format_of(w);
@@ -337,7 +372,7 @@ int ww_read_wav_batch_host(ww_wav_reader* r, const char* const* paths, int64_t n
     j.paths = paths; j.n = n; j.slot = &s; j.status = status_host; j.capacity = r->max_raw;
     run_job(r, &j);
     s.n = n;
-    const int64_t need = j.need.load();
+    const int64_t need = j.cursor.load();                      // every usable file reserved its aligned size, whether it fitted or not
     s.raw_bytes = need < r->max_raw ? need : r->max_raw;
     if (raw_bytes_out) *raw_bytes_out = need;
     if (descs_host_out) *descs_host_out = s.descs_host;

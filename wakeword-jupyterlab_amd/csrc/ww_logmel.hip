@@ -315,6 +315,14 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
 #endif
             dft8(za);
             dft8(zb);
+#ifdef WW_K1_ABL_NOX1                  // timing-only ablation: exchange 1 without its LDS round trip (results are garbage)
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) {
+                const float4 t = t1[k1 - 1];
+                za[k1] = cmul(za[k1], make_float2(t.x, t.y));
+                zb[k1] = cmul(zb[k1], make_float2(t.z, t.w));
+            }
+#else
             slab4[lane] = make_float4(za[0].x, za[0].y, zb[0].x, zb[0].y);
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) {
@@ -323,6 +331,7 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
                 const float2 b = cmul(zb[k1], make_float2(t.z, t.w));
                 slab4[k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)))] = make_float4(a.x, a.y, b.x, b.y);
             }
+#endif
             lds_order();
             STAMP(0);
             // ---- pass 2: lane = (k1, j): radix 8 over n2 of y[k1][16 n2 + 2j + q]; twiddle W_128; store X2 ----
@@ -331,19 +340,25 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
                 const int s8 = 8 * ((k1r >> 1) & 1);
                 const float4* x1e = slab4 + k1r * 64 + jr + s8;
                 const float4* x1o = slab4 + k1r * 64 + jr - s8;
+#ifndef WW_K1_ABL_NOX1
 #pragma unroll
                 for (int n2 = 0; n2 < 8; ++n2) {
                     const float4 v = (n2 & 1) ? x1o[n2 * 8] : x1e[n2 * 8];
                     za[n2] = make_float2(v.x, v.y);
                     zb[n2] = make_float2(v.z, v.w);
                 }
+#else
+                asm volatile("" :: "v"(x1e), "v"(x1o));
+#endif
                 float4 t2[7];
 #pragma unroll
                 for (int k2 = 1; k2 < 8; ++k2) t2[k2 - 1] = tw2_4[(k2 - 1) * 8 + jr];
                 lds_order();
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef WW_K1_ABL_NODFT8P2             // timing-only ablation: pass 2's butterflies
                 dft8(za);
                 dft8(zb);
+#endif
                 // writer (k1, j), reader lane 8 k1 + k2, slot j ^ ((reader >> 1) & 7) = j ^ (4 (k1 & 1) + (k2 >> 1)):
                 // four lane bases (one per k2 >> 1), everything else is an immediate offset
                 float4* x2w[4];
@@ -357,7 +372,11 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
                         a = cmul(a, make_float2(t.x, t.y));
                         b = cmul(b, make_float2(t.z, t.w));
                     }
+#ifdef WW_K1_ABL_NOX2                  // timing-only ablation: exchange 2 without its LDS round trip
+                    za[k2] = a; zb[k2] = b;
+#else
                     x2w[k2 >> 1][8 * k2] = make_float4(a.x, a.y, b.x, b.y);
+#endif
                 }
             }
             lds_order();
@@ -366,14 +385,22 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
             {
                 float2 u[16];
                 const int sw2 = (lane >> 1) & 7;
+#ifdef WW_K1_ABL_NOX2
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { u[2 * m] = za[m]; u[2 * m + 1] = zb[m]; }
+                asm volatile("" :: "v"(sw2));
+#else
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const float4 v = slab4[lane * 8 + (m ^ sw2)];
                     u[2 * m] = make_float2(v.x, v.y);
                     u[2 * m + 1] = make_float2(v.z, v.w);
                 }
+#endif
                 lds_order();
+#ifndef WW_K1_ABL_NODFT16              // timing-only ablation: what pass 3's butterflies cost the vector ALU (results are garbage)
                 dft16(u);
+#endif
                 const int lp = (lane >> 3) + 8 * (lane & 7);
                 float2* zw = slab2 + (lp ^ (((lp >> 4) & 3) << 1));     // bits 4-5 of k = lp + 64 kk are lp's: one base
 #pragma unroll
@@ -778,7 +805,9 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
                     u[2 * m + 1] = v.b;
                 }
                 lds_order();
+#ifndef WW_K1_ABL_NODFT16              // timing-only ablation: what pass 3's butterflies cost the vector ALU (results are garbage)
                 dft16(u);
+#endif
                 const int lp = (lane >> 3) + 8 * (lane & 7);
                 cd* zw = slabc + (lp ^ (((lp >> 4) & 3) << 1));
 #pragma unroll
