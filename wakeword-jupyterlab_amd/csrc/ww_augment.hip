@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ in
         for (int q = 0; q < 4; ++q) {
             const uint64_t j = uint64_t(i + q) + 1ull;
             const uint32_t w1 = uint32_t(mix64(k1 + j * 0x9E3779B97F4A7C15ull) >> 32), w2 = uint32_t(mix64(k2 + j * 0x9E3779B97F4A7C15ull) >> 32);
-            const float u1 = (float(w1 >> 8) + 0.5f + float(w1 & 0xffu) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);   // (w1 + 0.5) / 2^32 to float32
+            const float u1 = (float(w1 >> 8) + (float(w1 & 0xffu) + 0.5f) * (1.0f / 256.0f)) * (1.0f / 16777216.0f);   // (w1 + 0.5) / 2^32 to float32
             const float u2 = (float(w2 >> 8) + float(w2 & 0xffu) * (1.0f / 256.0f)) * (1.0f / 16777216.0f) + (0.5f / 4294967296.0f);
             const float nrm = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
             pv[q] = fmaf(sigma, nrm, pv[q]);

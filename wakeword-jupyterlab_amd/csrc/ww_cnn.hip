@@ -673,7 +673,10 @@ extern "C" __attribute__((visibility("default"))) int ww_debug_cnn_stamps(unsign
 // v_writelane_b32: the wave-uniform value goes into ONE lane of the register (no clang builtin in this toolchain)
 template <int LANE>
 __device__ __forceinline__ uint32_t write_lane(uint32_t uniform_value, uint32_t reg) {
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(uniform_value), "n"(LANE));      // lane select: an inline constant
+    // s_nop 1: on gfx950 a VALU write of an SGPR (a v_cmp's ballot) needs two wait states before a VALU instruction reads it; the compiler
+    // pads its own instructions but does not see the operands of inline asm.  (Round 3: a width-32 copy of the mask epilogue fed the
+    // ballots straight from v_cmp into this instruction and stored wrong bits; with an s_and in between, as now, it happened to be safe.)
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(uniform_value), "n"(LANE));      // lane select: an inline constant
     return reg;
 }
 // ------------------------------------------------------------------------------------------------
@@ -956,50 +959,44 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             // output transform + bias + 2*relu + pool (D: lane & 15 = channel, register j <-> column 16 c + 4 kq + j)
             const int trow = kWPerProd * (2 * grp + (sq & 1)) + (sq >> 1);      // the tile row this step holds (producer 2 grp + (sq & 1), its i-th)
             float pv[8];                                        // the tile row's eight (v0 + v1) pairs: summed as a tree, then into `pool`
-            // width == 32 (every clip of the mel path) runs a copy of the epilogue without the eight column selects
-            auto epilogue = [&](auto fullw) {
-                constexpr bool FULLW = decltype(fullw)::value;
-    #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    unsigned long long live0[4], live1[4];
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float m12 = acc[1][c][j] + acc[2][c][j], m1m2 = acc[1][c][j] - acc[2][c][j];
-                        const float y0 = acc[0][c][j] + m12, y1 = m1m2 - acc[3][c][j];
-                        const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
-                        const bool col_live = FULLW || 16 * c + 4 * kq + j < width;
-                        if constexpr (POOL) {
-                            pv[4 * c + j] = col_live ? v0 + v1 : 0.f;
-                        } else {
-                            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                            float* o = out + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + j) * 64 + 16 * nt + pi;
-                            o[0] = col_live ? 0.5f * v0 : 0.f;
-                            o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
-                        }
-                        if constexpr (BITS) {       // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
-                            live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
-                            live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
-                        }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned long long live0[4], live1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float m12 = acc[1][c][j] + acc[2][c][j], m1m2 = acc[1][c][j] - acc[2][c][j];
+                    const float y0 = acc[0][c][j] + m12, y1 = m1m2 - acc[3][c][j];
+                    const float v0 = relu2(fmaf(y0, dsc, bias)), v1 = relu2(fmaf(y1, dsc, bias));
+                    const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
+                    if constexpr (POOL) {
+                        pv[4 * c + j] = col_live ? v0 + v1 : 0.f;
+                    } else {
+                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                        float* o = out + ((clip * kH + 2 * trow) * kW + 16 * c + 4 * kq + j) * 64 + 16 * nt + pi;
+                        o[0] = col_live ? 0.5f * v0 : 0.f;
+                        o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
                     }
-                    if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
-                        uint32_t word = 0u;
-                        word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
-                        word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
-                        word = write_lane<4>(uint32_t(live0[2]), word);  word = write_lane<5>(uint32_t(live0[2] >> 32), word);
-                        word = write_lane<6>(uint32_t(live0[3]), word);  word = write_lane<7>(uint32_t(live0[3] >> 32), word);
-                        word = write_lane<8>(uint32_t(live1[0]), word);  word = write_lane<9>(uint32_t(live1[0] >> 32), word);
-                        word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
-                        word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
-                        word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
-                        if (lane < 16) {
-                            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                            reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16) + lane] = word;
-                        }
+                    if constexpr (BITS) {       // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
+                        live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
+                        live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
                     }
                 }
-            };
-            if (width == kW) epilogue(std::true_type{});
-            else epilogue(std::false_type{});
+                if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
+                    uint32_t word = 0u;
+                    word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
+                    word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
+                    word = write_lane<4>(uint32_t(live0[2]), word);  word = write_lane<5>(uint32_t(live0[2] >> 32), word);
+                    word = write_lane<6>(uint32_t(live0[3]), word);  word = write_lane<7>(uint32_t(live0[3] >> 32), word);
+                    word = write_lane<8>(uint32_t(live1[0]), word);  word = write_lane<9>(uint32_t(live1[0] >> 32), word);
+                    word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
+                    word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
+                    word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
+                    if (lane < 16) {
+                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                        reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16) + lane] = word;
+                    }
+                }
+            }
             if constexpr (POOL) pool += tree8(pv);
             if (POOL && sq == kWPerGroup - 1) {               // this wave's last tile row of the clip
                 float p2 = pool + __shfl_xor(pool, 16);
