@@ -158,3 +158,38 @@ def test_crop_draw_uses_python_random_like_pad_or_truncate():
     random.seed(5); want = random.randint(0, 32000 - 16000); random.seed(5)
     files.WavBatchReader.draw_crops(descs, status)
     assert list(descs["crop_start"]) == [0, want, 0]
+
+
+def test_reader_is_clean_under_thread_sanitizer(tmp_path):
+    """The reader's own source built -fsanitize=thread (plain C++, CPU only) and driven by tests/c/reader_tsan_harness.cpp: 8 threads,
+    3 slots, 30 rounds over 302 files (two of them unusable).  Any data race in the pool / bump allocator / status writes is a report."""
+    import shutil
+    import subprocess
+    import torch
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ with a ThreadSanitizer runtime")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc, libdir = os.path.join(root, "wakeword-jupyterlab_amd", "csrc"), os.path.join(root, "wakeword-jupyterlab_amd")
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+    obj, exe = os.path.join(tmp_path, "files_tsan.o"), os.path.join(tmp_path, "reader_tsan")
+    common = [clang, "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I", os.path.join(root, "include")]
+    subprocess.run(common + ["-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", csrc, "-DWW_BUILD", "-x", "c++", "-c",
+                             os.path.join(csrc, "ww_files.cpp"), "-o", obj], check=True, capture_output=True, text=True)
+    subprocess.run(common + [os.path.join(root, "tests", "c", "reader_tsan_harness.cpp"), obj, "-o", exe, "-L", libdir, "-l:libwakeword_amd.so",
+                             "-Wl,-rpath," + libdir, "-L", tl, "-Wl,-rpath," + tl, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"],
+                   check=True, capture_output=True, text=True)
+    r = np.random.default_rng(0)
+    paths = []
+    for i in range(300):
+        p = os.path.join(tmp_path, f"t{i:03d}.wav")
+        with open(p, "wb") as f:
+            f.write(_wav(r.integers(-2 ** 15, 2 ** 15 - 1, 200 + 37 * (i % 53)).astype("<i2").tobytes()))
+        paths.append(p)
+    bad = os.path.join(tmp_path, "bad.wav")
+    with open(bad, "wb") as f:
+        f.write(b"junk")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", LD_LIBRARY_PATH=tl + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe] + paths + [bad, os.path.join(tmp_path, "missing.wav")], capture_output=True, text=True, env=env, timeout=300)
+    assert "WARNING: ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+    assert out.returncode == 0 and "READER_TSAN_OK 9000" in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
