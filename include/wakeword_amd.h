@@ -92,7 +92,11 @@ WW_API int ww_sync_timeouts(void);
  *                       of the weights); under F16X3_DIRECT every convolution of both models is direct. */
 #define WW_CONV_MATH_F16X3_DIRECT 2
 WW_API int ww_set_conv_math(int mode);
-WW_API int ww_get_conv_math(void);
+WW_API int ww_get_conv_math(void);   /* what a launch from the calling thread would use now (its override, else the process default) */
+/* Per-thread override of the process-wide setting: launches issued by the CALLING THREAD use `mode` until it is cleared with
+ * WW_MATH_INHERIT; other threads are unaffected.  A launch reads its mode once.  (ww_set_logmel_math_thread: the same for K1.) */
+#define WW_MATH_INHERIT (-1)
+WW_API int ww_set_conv_math_thread(int mode);
 
 /* Arithmetic of the log-mel front end (K1), process-wide, default AUTO.  The reference's STFT is float64 (librosa forms
  * window * frame in float64 and numpy.fft.rfft runs in double; wakeword_training_script.py:89-98), then everything is
@@ -113,6 +117,7 @@ WW_API int ww_get_conv_math(void);
 #define WW_LOGMEL_MATH_AUTO 2
 WW_API int ww_set_logmel_math(int mode);
 WW_API int ww_get_logmel_math(void);
+WW_API int ww_set_logmel_math_thread(int mode);
 
 /* ---- front-end tables, host side (no GPU needed; lets CPU tests check them) ------------------ */
 /* librosa.filters.mel(sr=16000, n_fft=2048, n_mels=80, fmin=0, fmax=8000, htk=False,
@@ -131,6 +136,7 @@ WW_API int ww_hann_window_host(float* out_host);
 #define WW_FMT_S32 3
 #define WW_FMT_F32 4
 #define WW_FMT_U8 5
+#define WW_FMT_F64 6 /* IEEE double samples (WAVE_FORMAT_IEEE_FLOAT, 64 bits): rounded to float32 as soundfile does for dtype float32 */
 typedef struct ww_clip_desc {
     int64_t byte_offset;  /* start of the interleaved sample data of this file inside raw_dev */
     int64_t n_frames;     /* sample frames in the file */
@@ -169,7 +175,7 @@ WW_API int ww_decode_resample(const uint8_t* raw_dev, const ww_clip_desc* descs_
 #define WW_WAV_EOPEN (-1)    /* cannot open */
 #define WW_WAV_ENOTRIFF (-2) /* not a RIFF/WAVE file */
 #define WW_WAV_ECHUNK (-3)   /* fmt or data chunk missing / truncated */
-#define WW_WAV_EFORMAT (-4)  /* encoding K0 does not take (it takes PCM u8/s16/s24/s32 and float32), or an absurd rate */
+#define WW_WAV_EFORMAT (-4)  /* encoding K0 does not take (it takes PCM u8/s16/s24/s32 and float32/float64), or an absurd rate */
 #define WW_WAV_EIO (-5)      /* read error */
 #define WW_WAV_ESPACE (-6)   /* the staging buffer was full (the call then returns WW_ENOSPACE with the size needed) */
 typedef struct ww_wav_reader ww_wav_reader;

@@ -19,7 +19,9 @@ pytestmark = pytest.mark.gpu
 
 def _write_wav(path, x, sr=16000, bits=16, channels=1, fmt=1):
     x = np.asarray(x, dtype=np.float64).reshape(-1, channels)
-    if fmt == 3:
+    if fmt == 3 and bits == 64:
+        raw = x.astype("<f8").tobytes()
+    elif fmt == 3:
         raw, bits = x.astype("<f4").tobytes(), 32
     elif bits == 16:
         raw = np.clip(np.round(x * 32767), -32768, 32767).astype("<i2").tobytes()
@@ -45,7 +47,7 @@ CASES = [  # (name, sr, seconds, channels, bits, fmt)
     ("s16_16k", 16000, 1.0, 1, 16, 1), ("s16_16k_short", 16000, 0.4, 1, 16, 1), ("s16_16k_long", 16000, 2.3, 1, 16, 1),
     ("f32_16k_stereo", 16000, 1.0, 2, 32, 3), ("u8_16k", 16000, 0.7, 1, 8, 1), ("s24_16k", 16000, 1.0, 1, 24, 1),
     ("s32_16k", 16000, 0.9, 1, 32, 1), ("s16_44k", 44100, 1.3, 1, 16, 1), ("s16_48k_stereo", 48000, 0.8, 2, 16, 1),
-    ("s16_8k", 8000, 1.0, 1, 16, 1), ("s16_22k_long", 22050, 1.9, 1, 16, 1),
+    ("s16_8k", 8000, 1.0, 1, 16, 1), ("s16_22k_long", 22050, 1.9, 1, 16, 1), ("f64_16k", 16000, 0.6, 1, 64, 3), ("f64_32k_stereo", 32000, 1.1, 2, 64, 3),
 ]
 
 

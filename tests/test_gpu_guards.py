@@ -270,6 +270,57 @@ def test_nan_and_inf_inputs_propagate_like_the_reference(dev, conv_math):
     assert np.isnan(y[1]).all() and not np.isfinite(y[3]).any()        # NaN stays NaN; inf -> inf - inf = NaN in the reference too
 
 
+def test_per_thread_math_overrides_do_not_leak_between_threads(dev):
+    """Two host threads with different per-thread conv arithmetics (and one with a log-mel override) launch concurrently on their own
+    streams for a while: each must get, bit for bit, what a single-threaded run under that arithmetic gives, and the process default is
+    untouched (the process-wide switches were unsafe for a streamer beside a batch job)."""
+    import threading
+    from wakeword_jupyterlab_amd import ops
+    sd = _sd("simple")
+    packed = torch.from_numpy(ops.pack_state_dict(sd)).to(dev)
+    x = torch.from_numpy(_inputs_case("logmel", batch=96)).to(dev)
+    pcm = torch.from_numpy(pkg.synth.make_clips(500, 24)).to(dev)
+    want = {}
+    for m in ("f16x3", "f16x3d", "f32"):
+        ops.set_conv_math(m)
+        want[m] = ops.cnn_pool(x, packed, 2).clone()
+    ops.set_conv_math("f16x3")
+    ops.set_logmel_math("f64")
+    want_mel64 = ops.logmel(pcm, True).clone()
+    ops.set_logmel_math("auto")
+    want_mel = ops.logmel(pcm, True).clone()
+    assert not torch.equal(want["f16x3"], want["f32"])
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(mode, mel_mode):
+        try:
+            torch.cuda.set_device(dev)
+            ops.set_conv_math_thread(mode)
+            ops.set_logmel_math_thread(mel_mode)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(60):
+                    got = ops.cnn_pool(x, packed, 2)
+                    mel = ops.logmel(pcm, True)
+                    torch.cuda.current_stream().synchronize()
+                    if not torch.equal(got, want[mode]) or not torch.equal(mel, want_mel64 if mel_mode == "f64" else want_mel):
+                        errors.append(mode)
+                        return
+            ops.set_conv_math_thread(None)
+            ops.set_logmel_math_thread(None)
+        except Exception as e:                       # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=a) for a in (("f32", "f64"), ("f16x3d", None), ("f16x3", None))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert ops.get_conv_math() == "f16x3" and ops.get_logmel_math() == "auto"          # this thread and the process default: untouched
+    assert torch.equal(ops.cnn_pool(x, packed, 2), want["f16x3"])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # single clips of any length (the stride argument of the C ABI is irrelevant for one row)
 # ---------------------------------------------------------------------------------------------------------------

@@ -47,8 +47,9 @@ def corpus(tmp_path):
         "ext.wav": _wav(s16(3000), extensible=True),
         "cut.wav": _wav(s16(2000), data_size=100000),                         # header promises more than the file holds
         "empty.wav": _wav(b""),
-        # unusable
         "f64.wav": _wav(r.standard_normal(10).astype("<f8").tobytes(), bits=64, tag=3),
+        # unusable
+        "alaw.wav": _wav(r.integers(0, 255, 100).astype(np.uint8).tobytes(), bits=8, tag=6),
         "notwav.wav": b"this is not a wave file at all",
         "nodata.wav": b"RIFF" + struct.pack("<I", 4 + 24) + b"WAVE" + _chunk(b"fmt ", struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)),
         "tiny.wav": b"RIFF",
@@ -63,8 +64,8 @@ def corpus(tmp_path):
     return paths, cases
 
 
-FMT_OF = {(1, 16): nat.FMT_S16, (1, 24): nat.FMT_S24, (1, 32): nat.FMT_S32, (3, 32): nat.FMT_F32, (1, 8): nat.FMT_U8}
-EXPECT_BAD = {"f64.wav": -4, "notwav.wav": -2, "nodata.wav": -3, "tiny.wav": -2, "missing.wav": -1}
+FMT_OF = {(1, 16): nat.FMT_S16, (1, 24): nat.FMT_S24, (1, 32): nat.FMT_S32, (3, 32): nat.FMT_F32, (1, 8): nat.FMT_U8, (3, 64): nat.FMT_F64}
+EXPECT_BAD = {"alaw.wav": -4, "notwav.wav": -2, "nodata.wav": -3, "tiny.wav": -2, "missing.wav": -1}
 
 
 @pytest.mark.parametrize("threads", [1, 4])

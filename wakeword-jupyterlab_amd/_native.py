@@ -74,7 +74,7 @@ class AugmentPlan(C.Structure):
     ]
 
 
-FMT_S16, FMT_S24, FMT_S32, FMT_F32, FMT_U8 = 1, 2, 3, 4, 5
+FMT_S16, FMT_S24, FMT_S32, FMT_F32, FMT_U8, FMT_F64 = 1, 2, 3, 4, 5, 6
 WAV_STATUS = {1: "ok", -1: "cannot open", -2: "not a RIFF/WAVE file", -3: "missing fmt/data chunk", -4: "unsupported WAV encoding",
               -5: "read error", -6: "staging buffer full"}
 
@@ -85,6 +85,8 @@ PROTOTYPES = {
     "ww_init": (C.c_int, []),
     "ww_set_conv_math": (C.c_int, [C.c_int]),
     "ww_get_conv_math": (C.c_int, []),
+    "ww_set_conv_math_thread": (C.c_int, [C.c_int]),
+    "ww_set_logmel_math_thread": (C.c_int, [C.c_int]),
     "ww_set_train_math": (C.c_int, [C.c_int]),
     "ww_get_train_math": (C.c_int, []),
     "ww_set_logmel_math": (C.c_int, [C.c_int]),

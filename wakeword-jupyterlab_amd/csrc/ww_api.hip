@@ -5,6 +5,8 @@
 #include <mutex>
 #include <new>
 
+#include <atomic>
+
 #include "ww_internal.h"
 
 namespace ww {
@@ -68,15 +70,18 @@ const LogmelTables* device_tables() {
     return devp;
 }
 
-static int g_conv_math = WW_CONV_MATH_F16X3;
+// Process-wide defaults (atomics: set from any thread) and per-thread overrides (WW_MATH_INHERIT = none): a launch reads its mode ONCE,
+// the calling thread's override first -- two host threads (a streamer and a batch job) can use different arithmetics safely.
+static std::atomic<int> g_conv_math{WW_CONV_MATH_F16X3};
+static thread_local int t_conv_math = WW_MATH_INHERIT, t_logmel_math = WW_MATH_INHERIT;
 static int g_train_math = WW_TRAIN_MATH_F16X3;
 int train_math_mode() { return g_train_math; }
-int conv_math_mode() { return g_conv_math; }
-void set_conv_math_mode(int mode) { g_conv_math = mode; }
+int conv_math_mode() { return t_conv_math != WW_MATH_INHERIT ? t_conv_math : g_conv_math.load(std::memory_order_relaxed); }
+void set_conv_math_mode(int mode) { g_conv_math.store(mode, std::memory_order_relaxed); }
 
-static int g_logmel_math = WW_LOGMEL_MATH_AUTO;
-int logmel_math_mode() { return g_logmel_math; }
-void set_logmel_math_mode(int mode) { g_logmel_math = mode; }
+static std::atomic<int> g_logmel_math{WW_LOGMEL_MATH_AUTO};
+int logmel_math_mode() { return t_logmel_math != WW_MATH_INHERIT ? t_logmel_math : g_logmel_math.load(std::memory_order_relaxed); }
+void set_logmel_math_mode(int mode) { g_logmel_math.store(mode, std::memory_order_relaxed); }
 
 static int64_t align256(int64_t b) { return (b + 255) & ~int64_t(255); }
 int64_t cnn_scratch_bytes(int64_t n, int n_conv);
@@ -196,6 +201,12 @@ int ww_set_conv_math(int mode) {
     return WW_OK;
 }
 int ww_get_conv_math(void) { return conv_math_mode(); }
+int ww_set_conv_math_thread(int mode) {
+    if (mode != WW_MATH_INHERIT && mode != WW_CONV_MATH_F32 && mode != WW_CONV_MATH_F16X3 && mode != WW_CONV_MATH_F16X3_DIRECT)
+        return fail(WW_EINVAL, "unknown conv math mode %d", mode);
+    t_conv_math = mode;
+    return WW_OK;
+}
 int ww_set_train_math(int mode) {
     if (mode != WW_TRAIN_MATH_F32 && mode != WW_TRAIN_MATH_F16X3) return fail(WW_EINVAL, "train math %d: expected WW_TRAIN_MATH_F32 or WW_TRAIN_MATH_F16X3", mode);
     g_train_math = mode;
@@ -210,6 +221,12 @@ int ww_set_logmel_math(int mode) {
     return WW_OK;
 }
 int ww_get_logmel_math(void) { return logmel_math_mode(); }
+int ww_set_logmel_math_thread(int mode) {
+    if (mode != WW_MATH_INHERIT && mode != WW_LOGMEL_MATH_F32 && mode != WW_LOGMEL_MATH_F64 && mode != WW_LOGMEL_MATH_AUTO)
+        return fail(WW_EINVAL, "unknown log-mel math mode %d", mode);
+    t_logmel_math = mode;
+    return WW_OK;
+}
 
 int ww_init(void) {
     if (int rc = require_gfx950()) return rc;

@@ -1524,10 +1524,11 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
     if (int rc = opt_in_lds()) return rc;
     const int cus = device_cu_count();
     const int grid1 = int(n < cus ? n : cus);                  // persistent: one workgroup per CU
-    if (conv_math_mode() != 0) {                               // f16x3
+    const int cmath = conv_math_mode();                        // read once per launch (thread override, else the process default)
+    if (cmath != 0) {                                          // f16x3
         const u32x4* w1h = reinterpret_cast<const u32x4*>(packed + L.conv1_h);
         const u32x4* w2h = reinterpret_cast<const u32x4*>(packed + L.conv2_h16);
-        if (conv_math_mode() == 1) {                           // conv2 (and conv3) as 1-D Winograd
+        if (cmath == 1) {                                      // conv2 (and conv3) as 1-D Winograd
             const u32x4* w2w = reinterpret_cast<const u32x4*>(packed + L.conv2_hw);
             if (n_conv == 2) {
                 hipLaunchKernelGGL(cnn2w_kernel<true>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,

@@ -101,6 +101,7 @@ __device__ __forceinline__ float sample_mono(const uint8_t* __restrict__ p, int6
                 break;
             }
             case WW_FMT_S32: v = float(reinterpret_cast<const int32_t*>(p)[i]) * (1.0f / 2147483648.0f); break;
+            case WW_FMT_F64: v = float(reinterpret_cast<const double*>(p)[i]); break;
             default:         v = reinterpret_cast<const float*>(p)[i]; break;
         }
         s += v;

@@ -111,6 +111,7 @@ static int format_of(const WavInfo& w) {
     if (w.tag == 1 && w.bits == 24) return WW_FMT_S24;
     if (w.tag == 1 && w.bits == 32) return WW_FMT_S32;
     if (w.tag == 3 && w.bits == 32) return WW_FMT_F32;
+    if (w.tag == 3 && w.bits == 64) return WW_FMT_F64;
     if (w.tag == 1 && w.bits == 8) return WW_FMT_U8;
     return 0;
 }

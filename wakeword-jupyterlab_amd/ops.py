@@ -377,6 +377,14 @@ def set_conv_math(mode: str) -> None:
     nat.check(nat.lib.ww_set_conv_math(CONV_MATH[mode]))
 
 
+def set_conv_math_thread(mode) -> None:
+    """Override the conv arithmetic for launches issued by the CALLING THREAD only (None clears it): a streamer thread and a batch
+    job can then use different arithmetics safely."""
+    if mode is not None and mode not in CONV_MATH:
+        raise ValueError(f"conv math {mode!r}: expected one of {sorted(CONV_MATH)} or None")
+    nat.check(nat.lib.ww_set_conv_math_thread(-1 if mode is None else CONV_MATH[mode]))
+
+
 def get_conv_math() -> str:
     return {v: k for k, v in CONV_MATH.items()}[nat.lib.ww_get_conv_math()]
 
@@ -391,6 +399,13 @@ def set_logmel_math(mode: str) -> None:
     if mode not in LOGMEL_MATH:
         raise ValueError(f"log-mel math {mode!r}: expected one of {sorted(LOGMEL_MATH)}")
     nat.check(nat.lib.ww_set_logmel_math(LOGMEL_MATH[mode]))
+
+
+def set_logmel_math_thread(mode) -> None:
+    """Per-thread override of the log-mel arithmetic (None clears it); see set_conv_math_thread."""
+    if mode is not None and mode not in LOGMEL_MATH:
+        raise ValueError(f"log-mel math {mode!r}: expected one of {sorted(LOGMEL_MATH)} or None")
+    nat.check(nat.lib.ww_set_logmel_math_thread(-1 if mode is None else LOGMEL_MATH[mode]))
 
 
 def get_logmel_math() -> str:
