@@ -484,9 +484,13 @@ __global__ void lstm_gates_bwd_kernel(const float* __restrict__ dhd, const float
 // through LDS in the fixed order 0, 1, 2, 3.  Rows / columns beyond M / N load zeros and are not stored.
 // ------------------------------------------------------------------------------------------------
 // rowsum (nullable): rowsum[m] = sum_k A(m,k) in the same fixed order -- the bias gradients are the row sums of the weight-gradient GEMMs' A.
+// Split K (round 3): the weight-gradient GEMMs have K = the batch (4096) and only 8-256 output tiles, i.e. one 4-wave workgroup per CU or
+// fewer, each waiting out its own global loads (0.31 ms for the six GEMMs, ~11 % of the f32 matrix peak).  gridDim.z = S slices of K, each
+// slice writes its partial tile to `part` ([S][M][N], + [S][M] row sums), combine_splitk_kernel adds the slices in the fixed order 0..S-1:
+// S times the waves and loads in flight per CU, still bitwise repeatable.  S = 1 writes C directly.
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B,
                                                         int64_t sbk, int64_t sbn, float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                        float* __restrict__ rowsum) {
+                                                        float* __restrict__ rowsum, float* __restrict__ part) {
     __shared__ float xch[3][16][64];
     __shared__ float rs[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -499,8 +503,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     float asum = 0.f;
-    const int pairs = (K + 1) / 2;
-    int p = wave;
+    const int splits = int(gridDim.z), z = int(blockIdx.z);
+    const int all_pairs = (K + 1) / 2, per = (all_pairs + splits - 1) / splits;
+    const int p_begin = z * per, pairs = p_begin + per < all_pairs ? p_begin + per : all_pairs;      // this slice: k pairs [p_begin, pairs)
+    int p = p_begin + wave;
     for (; p + 28 < pairs; p += 32) {                        // eight k pairs per trip: sixteen loads in flight under the MFMAs
         float a[8], b[8];
 #pragma unroll
@@ -528,21 +534,58 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const float* __restrict_
     }
     __syncthreads();
     if (wave == 0) {
+        float* cdst = splits > 1 ? part + int64_t(z) * M * N : C;
+        const int64_t cld = splits > 1 ? N : ldc;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float v = ((acc[j] + xch[0][j][lane]) + xch[1][j][lane]) + xch[2][j][lane];
             const int m = m0 + (j & 3) + 8 * (j >> 2) + 4 * kk;          // D: lane & 31 = n, register j <-> row m
-            if (m < M && b_ok) C[int64_t(m) * ldc + n0 + mn] = v;
+            if (m < M && b_ok) cdst[int64_t(m) * cld + n0 + mn] = v;
         }
-        if (rowsum != nullptr && blockIdx.x == 0 && lane < 32 && a_ok)        // (wave 0..3) x (k parity 0, 1), fixed order
-            rowsum[m0 + lane] = (((rs[0][lane] + rs[0][lane + 32]) + (rs[1][lane] + rs[1][lane + 32])) + (rs[2][lane] + rs[2][lane + 32])) +
-                                (rs[3][lane] + rs[3][lane + 32]);
+        if (rowsum != nullptr && blockIdx.x == 0 && lane < 32 && a_ok) {       // (wave 0..3) x (k parity 0, 1), fixed order
+            const float r = (((rs[0][lane] + rs[0][lane + 32]) + (rs[1][lane] + rs[1][lane + 32])) + (rs[2][lane] + rs[2][lane + 32])) +
+                            (rs[3][lane] + rs[3][lane + 32]);
+            if (splits > 1) part[int64_t(splits) * M * N + int64_t(z) * M + m0 + lane] = r;
+            else rowsum[m0 + lane] = r;
+        }
     }
 }
 
+// C[m][n] = part[0][m][n] + part[1][m][n] + ... (fixed order); rowsum[m] likewise from the [S][M] block behind the tiles
+__global__ void combine_splitk_kernel(const float* __restrict__ part, int splits, int M, int N, float* __restrict__ C, int64_t ldc,
+                                      float* __restrict__ rowsum) {
+    const int64_t mn = int64_t(M) * N;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < mn + (rowsum ? M : 0); i += int64_t(gridDim.x) * blockDim.x) {
+        if (i < mn) {
+            float v = part[i];
+            for (int zz = 1; zz < splits; ++zz) v += part[int64_t(zz) * mn + i];
+            const int64_t m = i / N;
+            C[m * ldc + (i - m * N)] = v;
+        } else {
+            const int64_t m = i - mn;
+            const float* rp = part + int64_t(splits) * mn;
+            float v = rp[m];
+            for (int zz = 1; zz < splits; ++zz) v += rp[int64_t(zz) * M + m];
+            rowsum[m] = v;
+        }
+    }
+}
+
+// `part`: scratch of at least 8 * (M * N + M) floats for the GEMMs that are split (the reused gradient-partial block of the workspace)
 static void sgemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc, int M, int N, int K,
-                  hipStream_t st, float* rowsum = nullptr) {
-    hipLaunchKernelGGL(mfma_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, rowsum);
+                  hipStream_t st, float* rowsum = nullptr, float* part = nullptr) {
+    const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
+    int splits = 1;
+    if (part != nullptr && K >= 512) {
+        while (splits < 8 && tiles * splits < 1024 && K / (2 * splits) >= 128) splits *= 2;     // ~4 workgroups per CU, >= 64 k pairs per slice
+    }
+    hipLaunchKernelGGL(mfma_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, splits), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, rowsum,
+                       part);
+    if (splits > 1) {
+        const int64_t work = int64_t(M) * N + (rowsum ? M : 0);
+        hipLaunchKernelGGL(combine_splitk_kernel, dim3(unsigned((work + 255) / 256 < 1024 ? (work + 255) / 256 : 1024)), dim3(256), 0, st, part, splits, M,
+                           N, C, ldc, rowsum);
+    }
 }
 
 // gp[b][co] = dpooled[b][co] / (80 * width)
@@ -741,16 +784,19 @@ int train_backward(const float* mel, int64_t n, int width, const ww_train_params
     const bool bits = mode == WW_TRAIN_MATH_F16X3;       // the forward left bit images (and channels-last relu(conv2))
     const bool split = bits && nc == 2;                               // the kernels of ww_train_h.hip
     // fc: dW = dlogits^T hd1, db = the row sums of dlogits^T, dhd1 = dlogits W_fc
-    sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st, g->fc_bias);
+    // the split-K scratch: the gradient-partial block, not yet in use at this point of the backward (largest need: 8 x (1024 x 256 + 1024) floats)
+    float* gpart = w.partial;
+    static_assert(int64_t(kMaxGroups) * kWg2Partial >= 8 * (1024 * 256 + 1024), "split-K scratch fits the partial block");
+    sgemm(dlogits, 1, 2, w.hd1, H, 1, g->fc_weight, H, 2, H, N, st, g->fc_bias, gpart);
     sgemm(dlogits, 2, 1, p->fc_weight, H, 1, w.dhd1, H, N, H, 2, st);
     // layer 1
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(1024), dim3(256), 0, st, w.dhd1, w.gates1, w.mask1, N, w.dg1);
-    sgemm(w.dg1, 1, 4 * H, w.hd0, H, 1, g->lstm_weight_ih[1], H, 4 * H, H, N, st, g->lstm_bias[1]);   // [1024][256] = dg1^T hd0; bias = its A's row sums
-    sgemm(w.dg1, 4 * H, 1, p->lstm_weight_ih[1], H, 1, w.dhd0, H, N, H, 4 * H, st);            // [n][256] = dg1 W_ih_l1
+    sgemm(w.dg1, 1, 4 * H, w.hd0, H, 1, g->lstm_weight_ih[1], H, 4 * H, H, N, st, g->lstm_bias[1], gpart);   // [1024][256] = dg1^T hd0; bias = its A's row sums
+    sgemm(w.dg1, 4 * H, 1, p->lstm_weight_ih[1], H, 1, w.dhd0, H, N, H, 4 * H, st, nullptr, gpart);            // [n][256] = dg1 W_ih_l1
     // layer 0
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(1024), dim3(256), 0, st, w.dhd0, w.gates0, w.mask0, N, w.dg0);
-    sgemm(w.dg0, 1, 4 * H, w.pooled, c_last, 1, g->lstm_weight_ih[0], c_last, 4 * H, c_last, N, st, g->lstm_bias[0]);   // [1024][C] = dg0^T pooled
-    sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], c_last, 1, w.dpooled, c_last, N, c_last, 4 * H, st);      // [n][C] = dg0 W_ih_l0
+    sgemm(w.dg0, 1, 4 * H, w.pooled, c_last, 1, g->lstm_weight_ih[0], c_last, 4 * H, c_last, N, st, g->lstm_bias[0], gpart);   // [1024][C] = dg0^T pooled
+    sgemm(w.dg0, 4 * H, 1, p->lstm_weight_ih[0], c_last, 1, w.dpooled, c_last, N, c_last, 4 * H, st, nullptr, gpart);      // [n][C] = dg0 W_ih_l0
     if (bits) {
         if (int rc = launch_gp_max(w.dpooled, 1.0f / float(kTH * width), n, nc, w.gp, w.dgh, st)) return rc;
     } else {
