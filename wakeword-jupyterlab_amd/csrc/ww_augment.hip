@@ -263,30 +263,47 @@ __global__ __launch_bounds__(256) void istft_kernel(const float2* __restrict__ S
 // ------------------------------------------------------------------------------------------------
 constexpr int kKbZeros = 64, kKbTable = 512;
 constexpr int kKbLen = kKbZeros * kKbTable + 1;                  // 32,769 table entries
+// transposed table of resample_kernel: (step + 2) rows of R floats; step <= 512 -> R = 68; the pitch range's smallest step (scale 32/46) is 356 -> R = 96
+constexpr int kResampleLds = 150 * 1024;
 
-// One workgroup of 1024 threads per clip; the half-window lives in LDS (128 KiB).  Pitch-off clips copy through.
+// One workgroup of 1024 threads per clip.  Pitch-off clips copy through.
+// The taps of one output are the table entries offset + i * step, i = 0, 1, ... -- `step` = int(scale * 512) is the same for every
+// output of a clip, `offset` is a pseudo-random phase.  Round 2 kept the half-window in LDS in its natural order: one ds_read2_b32 per
+// tap at a random address per lane (3.5-way bank conflicts on average, 3.3 ms per 4096 clips, half of the augmentation).  Round 3 loads
+// it TRANSPOSED by phase, P[ph][i] = tab[ph + i * step] (rows of R floats, step + 2 rows: 137-145 KB): a lane's taps are consecutive in
+// its row, so four taps are one ds_read_b128 (two rows: the entry and its upper neighbour for the interpolation), and the four samples
+// one 16-byte global load.  Same weights, same fused multiply-adds in the same order: the results are bit-identical to the round-2 kernel.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));       // four consecutive samples at a 4-byte aligned address
+
 __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict__ Y, const AugDev* __restrict__ plan,
                                                         const LogmelTables* __restrict__ tb, const float* __restrict__ passthru,
                                                         float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float tab[];   // [kKbLen + 3]
+    extern __shared__ __attribute__((aligned(16))) float P[];   // [step + 2][R]
     const int clip = blockIdx.x, tid = threadIdx.x;
     float* o = out + int64_t(clip) * kClip;
     if (plan[clip].p_out == 0) {
         for (int i = tid; i < kClip; i += 1024) o[i] = passthru[int64_t(clip) * kClip + i];
         return;
     }
-    for (int i = tid; i < kKbLen; i += 1024) tab[i] = tb->kaiser_best[i];
-    if (tid < 3) tab[kKbLen + tid] = tb->kaiser_best[kKbLen - 1];     // np.diff(win) is padded with a 0
-    __syncthreads();
     const double ratio = plan[clip].p_ratio;
     const double scale = ratio < 1.0 ? ratio : 1.0;
     const int index_step = int(scale * kKbTable);
+    const int cnt = kKbLen / index_step + 1;                      // entries of row 0: i * step <= kKbLen
+    int R = (cnt + 3) & ~3;
+    if (((R >> 2) & 1) == 0) R += 4;                              // an odd number of 16-byte slots per row spreads the rows over the banks
+    // index kKbLen is the pad np.diff(win) gets (the last value again): tab[kKbLen] = tab[kKbLen - 1]
+    for (int i = 0; i < R; ++i)
+        for (int ph = tid; ph < index_step + 2; ph += 1024) {
+            const int j = ph + i * index_step;
+            P[ph * R + i] = (i < cnt && j <= kKbLen) ? tb->kaiser_best[j < kKbLen ? j : kKbLen - 1] : 0.f;
+        }
+    __syncthreads();
     const int n_orig = plan[clip].p_len, n_res = plan[clip].p_res;
     const float* y = Y + int64_t(clip) * kAugYStride;
     const double inv = 1.0 / ratio;
     for (int t = tid; t < kClip; t += 1024) {
-        // positions and table fractions in float64 (t / ratio needs ~15 integer + 9 fraction bits); the ~270 products per
-        // output are float32 FMAs in two independent chains
+        // positions and table fractions in float64 (t / ratio needs ~15 integer + 9 fraction bits); the ~140 products per
+        // output are float32 FMAs in two independent chains (left wing, right wing), each in tap order
         float accl = 0.f, accr = 0.f;
         const double time_register = double(t) * inv;
         const int n = int(time_register);
@@ -297,10 +314,22 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
             float eta = float(index_frac - double(offset));
             int i_max = (kKbLen - offset) / index_step;
             i_max = i_max < n + 1 ? i_max : n + 1;
-            for (int i = 0; i < i_max; ++i) {
-                const int idx = offset + i * index_step;
-                const float w0 = tab[idx], w1 = tab[idx + 1];
-                accl = fmaf(fmaf(eta, w1 - w0, w0), y[n - i], accl);
+            {
+                const float* r0 = P + offset * R;
+                const float* r1 = r0 + R;
+                int i = 0;
+                for (; i + 4 <= i_max; i += 4) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(r0 + i), t1 = *reinterpret_cast<const float4*>(r1 + i);
+                    const f4u yy = *reinterpret_cast<const f4u*>(y + n - i - 3);          // y[n-i-3 .. n-i]
+                    accl = fmaf(fmaf(eta, t1.x - t0.x, t0.x), yy.w, accl);
+                    accl = fmaf(fmaf(eta, t1.y - t0.y, t0.y), yy.z, accl);
+                    accl = fmaf(fmaf(eta, t1.z - t0.z, t0.z), yy.y, accl);
+                    accl = fmaf(fmaf(eta, t1.w - t0.w, t0.w), yy.x, accl);
+                }
+                for (; i < i_max; ++i) {
+                    const float w0 = r0[i], w1 = r1[i];
+                    accl = fmaf(fmaf(eta, w1 - w0, w0), y[n - i], accl);
+                }
             }
             frac = scale - frac;
             index_frac = frac * kKbTable;
@@ -308,10 +337,22 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
             eta = float(index_frac - double(offset));
             int k_max = (kKbLen - offset) / index_step;
             k_max = k_max < n_orig - n - 1 ? k_max : n_orig - n - 1;
-            for (int k = 0; k < k_max; ++k) {
-                const int idx = offset + k * index_step;
-                const float w0 = tab[idx], w1 = tab[idx + 1];
-                accr = fmaf(fmaf(eta, w1 - w0, w0), y[n + k + 1], accr);
+            {
+                const float* r0 = P + offset * R;
+                const float* r1 = r0 + R;
+                int k = 0;
+                for (; k + 4 <= k_max; k += 4) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(r0 + k), t1 = *reinterpret_cast<const float4*>(r1 + k);
+                    const f4u yy = *reinterpret_cast<const f4u*>(y + n + 1 + k);          // y[n+1+k .. n+4+k]
+                    accr = fmaf(fmaf(eta, t1.x - t0.x, t0.x), yy.x, accr);
+                    accr = fmaf(fmaf(eta, t1.y - t0.y, t0.y), yy.y, accr);
+                    accr = fmaf(fmaf(eta, t1.z - t0.z, t0.z), yy.z, accr);
+                    accr = fmaf(fmaf(eta, t1.w - t0.w, t0.w), yy.w, accr);
+                }
+                for (; k < k_max; ++k) {
+                    const float w0 = r0[k], w1 = r1[k];
+                    accr = fmaf(fmaf(eta, w1 - w0, w0), y[n + k + 1], accr);
+                }
             }
         }
         float acc = accl + accr;
@@ -446,7 +487,7 @@ int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const vo
         WW_HIP(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !attr[dev]) {
             WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIstftLds));
-            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (kKbLen + 3) * 4));
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kResampleLds));
             attr[dev] = true;
         }
     }
@@ -459,7 +500,7 @@ int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const vo
         hipLaunchKernelGGL(pv_kernel, dim3(unsigned(n)), dim3(256), 0, stream, D, plan, 0, S);
         hipLaunchKernelGGL(istft_kernel, dim3(unsigned(n)), dim3(256), kIstftLds, stream, S, plan, 0, tb,
                            static_cast<const float*>(nullptr), Y, int64_t(kAugYStride));
-        hipLaunchKernelGGL(resample_kernel, dim3(unsigned(n)), dim3(1024), (kKbLen + 3) * 4, stream, Y, plan, tb, cur, other);
+        hipLaunchKernelGGL(resample_kernel, dim3(unsigned(n)), dim3(1024), kResampleLds, stream, Y, plan, tb, cur, other);
         float* t = cur; cur = other; other = t;
     }
     if (any_stretch) {

@@ -676,7 +676,11 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t uniform_value, uint32_t 
     // s_nop 1: on gfx950 a VALU write of an SGPR (a v_cmp's ballot) needs two wait states before a VALU instruction reads it; the compiler
     // pads its own instructions but does not see the operands of inline asm.  (Round 3: a width-32 copy of the mask epilogue fed the
     // ballots straight from v_cmp into this instruction and stored wrong bits; with an s_and in between, as now, it happened to be safe.)
+#ifdef WW_ABL_WRITELANE_NONOP       // timing-only A/B: the instruction without its wait states
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(uniform_value), "n"(LANE));
+#else
     asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(uniform_value), "n"(LANE));      // lane select: an inline constant
+#endif
     return reg;
 }
 // ------------------------------------------------------------------------------------------------
