@@ -71,7 +71,7 @@ def measure_decode(batch=4096, steps=10, device=0):
 def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=None, tmp_root=None):
     """WAV files -> logits, end to end, page cache warm (the files were just written)."""
     import wakeword_jupyterlab_amd as pkg
-    from wakeword_jupyterlab_amd.files import WavBatchReader, default_threads
+    from wakeword_jupyterlab_amd.files import EncodedPaths, WavBatchReader, default_threads
     dev = torch.device("cuda", device)
     threads = threads or default_threads()
     sd = pkg.synth.make_state_dict("simple", seed=1234)
@@ -89,6 +89,7 @@ def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=
                 f.write(_wav_bytes(base[i % 64] * (1.0 - 0.004 * (i // 64))))
             paths.append(p)
         file_bytes = os.path.getsize(paths[0])
+        enc = EncodedPaths(paths)                    # the dataset's file list as the library takes it, converted once
         rd = WavBatchReader(max_clips=batch, max_raw_bytes=batch * (32000 + 64), threads=threads, slots=3, device=dev)
         n_b = n_files // batch
         pcm = [torch.empty((batch, 16000), device=dev) for _ in range(3)]
@@ -98,7 +99,7 @@ def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=
             for b in range(n_b):
                 t0 = time.perf_counter()
                 buf = pcm[b % 3]
-                _, ok = rd.load(paths[b * batch:(b + 1) * batch], normalize=True, out=buf, verbose=False)
+                _, ok = rd.load(enc, normalize=True, out=buf, verbose=False, lo=b * batch, hi=(b + 1) * batch)
                 t1 = time.perf_counter()
                 with torch.no_grad():
                     logits[b].copy_(m.forward_pcm(buf, normalize=False))         # K0 already normalised over the whole file
@@ -120,7 +121,7 @@ def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=
         t1 = time.perf_counter()
         for _ in range(2):
             for b in range(n_b):
-                rd.read(paths[b * batch:(b + 1) * batch], b % 3)
+                rd.read(enc, b % 3, b * batch, (b + 1) * batch)
         host_dt = (time.perf_counter() - t1) / 2
         rd.close()
         n = n_files * passes

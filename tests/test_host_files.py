@@ -139,6 +139,18 @@ def test_many_files_many_threads_are_all_accounted_for(tmp_path):
     rd.close()
 
 
+def test_encoded_paths_window_reads_the_same_files(corpus):
+    paths, _ = corpus
+    enc = files.EncodedPaths(paths)
+    rd = files.WavBatchReader(max_clips=64, max_raw_bytes=1 << 20, threads=3, host_only=True)
+    d_all, s_all = rd.read(paths, 0)
+    want = [(int(d["n_frames"]), int(d["sample_rate"]), int(st)) for d, st in zip(d_all, s_all)]
+    for lo, hi in ((0, len(paths)), (3, 9), (len(paths) - 2, len(paths)), (5, 5)):
+        d, st = rd.read(enc, 1, lo, hi)
+        assert [(int(a["n_frames"]), int(a["sample_rate"]), int(b)) for a, b in zip(d, st)] == want[lo:hi]
+    rd.close()
+
+
 def test_probe_reads_one_header(corpus):
     paths, cases = corpus
     for p in paths:

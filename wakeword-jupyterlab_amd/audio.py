@@ -194,16 +194,20 @@ class AudioProcessor:
             t = t.to(self._dev(), non_blocking=True)
         return ops.logmel(t, normalize)
 
-    def load_clips_gpu(self, paths, normalize: bool = True):
+    def load_clips_gpu(self, paths, normalize: bool = True, lo: int = 0, hi=None):
         """Host: the library's reader threads open the files, walk their RIFF headers and read the sample bytes into pinned
         staging (files.WavBatchReader -> ww_read_wav_batch_host).  GPU (kernel K0): sample conversion, mono mix, polyphase
         resample to 16 kHz, whole-file peak normalisation, random crop / zero pad to 1 s -- process_audio_file :125-133
-        up to the mel call.  Returns (device tensor [B, 16000], ok mask); unreadable files give a zero row, ok False."""
-        from .files import WavBatchReader
+        up to the mel call.  `paths`: a list, or a files.EncodedPaths with a window [lo, hi).  Returns (device tensor [B, 16000],
+        ok mask); unreadable files give a zero row, ok False."""
+        from .files import EncodedPaths, WavBatchReader
         dev = self._dev()
+        hi = len(paths) if hi is None else hi
         if getattr(self, "_reader", None) is None or self._reader.device != dev:
-            self._reader = WavBatchReader(max_clips=max(64, len(paths)), device=dev)
-        return self._reader.load(list(paths), normalize)
+            self._reader = WavBatchReader(max_clips=max(64, hi - lo), device=dev)
+        if not isinstance(paths, EncodedPaths):
+            paths = list(paths)
+        return self._reader.load(paths, normalize, lo=lo, hi=hi)
 
     def load_clips(self, paths, target_length=None):
         """Decode, peak-normalise and crop/pad a list of files on the host, in the reference's order

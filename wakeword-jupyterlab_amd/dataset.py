@@ -55,10 +55,13 @@ class WakewordDataset(Dataset):
         """Yield (data [B,1,80,32] on the GPU, target [B,1] on the GPU) in file order.
         gpu_decode=True: the host only reads bytes; decode/resample/normalise/crop run in kernel K0, log-mel in K1."""
         dev = self.processor._dev()
+        if gpu_decode and getattr(self, "_encoded", None) is None:
+            from .files import EncodedPaths
+            self._encoded = EncodedPaths(self.files)          # the file list as the native reader takes it, converted once
         for s in range(0, len(self.files), batch_size):
             paths = self.files[s:s + batch_size]
             if gpu_decode:
-                pcm_dev, ok = self.processor.load_clips_gpu(paths, normalize=True)
+                pcm_dev, ok = self.processor.load_clips_gpu(self._encoded, normalize=True, lo=s, hi=min(len(self.files), s + batch_size))
             else:
                 pcm, ok = self.processor.load_clips(paths)
                 pcm_dev = torch.from_numpy(pcm).to(dev)
