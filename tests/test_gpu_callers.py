@@ -186,6 +186,40 @@ def test_sharded_forward_pcm_two_ranks_on_one_gpu(tmp_path):
         assert "SHARDED_OK" in so, so[-2000:]
 
 
+def test_shuffling_loader_is_the_dataloader_line_without_workers(dev, tmp_path):
+    """`train_loader = DataLoader(train_dataset, batch_size=16, shuffle=True, num_workers=2)` (wakeword_training_script.py:461-463)
+    -> `train_loader = train_dataset.loader(batch_size=16, shuffle=True)`: same shapes per batch, every item exactly once per epoch, a new
+    order each epoch, and every (data, target) pair still belongs together (checked against the per-file oracle by content)."""
+    n = 37
+    paths, mels = [], []
+    for i in range(n):
+        x = pkg.synth.make_clip(700 + i)[: 16000 - 211 * (i % 7)] * 0.4
+        p = os.path.join(tmp_path, f"s{i:02d}.wav")
+        _write_wav16(p, x)
+        paths.append(p)
+        mels.append(_file_oracle(x))
+    ref = np.stack(mels)                                   # [n, 1?, 80, 32] by file index
+    ref = ref.reshape(n, 80, 32)
+    wake, neg = paths[:15], paths[15:]
+    ds = WakewordDataset(wake, neg, AudioProcessor(), verbose=False)
+    ld = ds.loader(batch_size=16, shuffle=True)
+    assert len(ld) == 3
+    orders = []
+    for epoch in range(2):
+        seen = []
+        for data, target in ld:
+            assert data.is_cuda and data.shape[1:] == (1, 80, 32) and target.shape == (data.shape[0], 1) and data.shape[0] in (16, 5)
+            got = data[:, 0].cpu().numpy()
+            for row, lab in zip(got, target[:, 0].tolist()):
+                j = int(np.argmin(np.abs(ref - row[None]).max(axis=(1, 2))))
+                assert np.abs(ref[j] - row).max() <= 1e-4 and lab == (1 if j < 15 else 0)
+                seen.append(j)
+        assert sorted(seen) == list(range(n))
+        orders.append(seen)
+    assert orders[0] != orders[1] and orders[0] != list(range(n))
+    assert [int(t) for _, tg in ds.loader(16) for t in tg[:, 0]] == ds.labels           # unshuffled: file order
+
+
 def test_rccl_gather_path_one_rank():
     """The RCCL path itself (`backend="nccl"`), executed: a fresh process with a one-rank RCCL group on this box's GPU runs the
     double-buffered async all-gather of bench.py's step (distributed.LogitsGatherPipeline) for seven steps, `sharded_forward_pcm`

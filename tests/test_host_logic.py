@@ -147,3 +147,21 @@ def test_synth_is_deterministic_and_follows_the_recipe():
     assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01
     t = pkg.synth.make_clips_tiled(0, 40, unique=16)
     assert t.shape == (40, 16000) and np.array_equal(t[:16], pkg.synth.make_clips(0, 16)) and not np.array_equal(t[16], t[0])
+
+
+def test_loader_epoch_order_follows_torch_generator():
+    """dataset.loader(): the reference's DataLoader(dataset, batch_size, shuffle=True) line (wakeword_training_script.py:461-463) without
+    worker processes -- lengths, drop_last, a fresh permutation per epoch that torch.manual_seed repeats (host logic only)."""
+    class NoGpu:
+        pass
+    ds = WakewordDataset([f"w{i}.wav" for i in range(5)], [f"n{i}.wav" for i in range(8)], NoGpu(), verbose=False)
+    assert (len(ds.loader(4)), len(ds.loader(4, drop_last=True)), len(ds.loader(16)), len(ds.loader(13))) == (4, 3, 1, 1)
+    assert ds.loader(4).order() == list(range(13))
+    ld = ds.loader(batch_size=4, shuffle=True, drop_last=True)
+    torch.manual_seed(3); a = ld.order()
+    torch.manual_seed(3); b = ld.order()
+    c = ld.order()
+    assert a == b and a != c and len(a) == 12 and len(set(a)) == 12
+    assert sorted(ds.loader(4, shuffle=True).order()) == list(range(13))
+    with pytest.raises(ValueError):
+        ds.loader(0)

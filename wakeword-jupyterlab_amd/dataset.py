@@ -2,9 +2,10 @@
 
 `dataset[idx]` returns `(FloatTensor [1, 80, 32], LongTensor [1])` exactly like the reference.  Because a
 GPU-backed `__getitem__` must not initialise HIP inside forked DataLoader workers, the per-item call is
-meant for `num_workers=0`; the fast path is `batches(batch_size)`, which decodes on the host and runs the
-log-mel kernel once per batch, yielding device tensors with `default_collate`'s shapes
-(`data [B,1,80,32]`, `target [B,1]`).
+meant for `num_workers=0`; the fast path is `loader(batch_size, shuffle)` (and `batches(batch_size)`, the same in file
+order): the library's reader threads feed kernels K0 / KA / K1 once per batch, yielding device tensors with
+`default_collate`'s shapes (`data [B,1,80,32]`, `target [B,1]`) -- the drop-in for the reference's
+`DataLoader(dataset, batch_size=16, shuffle=True, num_workers=2)` line.
 
 One deliberate deviation: when a file fails to load the reference substitutes `np.zeros((80, 31))`
 (:210-211), whose width (31) differs from real items (32) and makes `default_collate` raise.  Here the
@@ -54,25 +55,64 @@ class WakewordDataset(Dataset):
     def batches(self, batch_size=16, gpu_decode=True):
         """Yield (data [B,1,80,32] on the GPU, target [B,1] on the GPU) in file order.
         gpu_decode=True: the host only reads bytes; decode/resample/normalise/crop run in kernel K0, log-mel in K1."""
-        dev = self.processor._dev()
-        if gpu_decode and getattr(self, "_encoded", None) is None:
+        return iter(GpuBatchLoader(self, batch_size, shuffle=False, gpu_decode=gpu_decode))
+
+    def loader(self, batch_size=16, shuffle=False, drop_last=False):
+        """What `DataLoader(dataset, batch_size=.., shuffle=.., num_workers=2)` is to the reference's loops
+        (/root/reference/wakeword_training_script.py:461-463), without worker processes: an iterable with `len()`, re-iterable
+        (a new permutation per epoch when shuffle=True, drawn from torch's generator like RandomSampler: `torch.manual_seed`
+        repeats it), yielding `(data [B,1,80,32], target [B,1])` on the GPU.  Files are read by the library's reader threads into
+        pinned staging, decoded (K0), augmented when the dataset says so (KA) and turned into log-mel (K1) one batch at a time."""
+        return GpuBatchLoader(self, batch_size, shuffle=shuffle, drop_last=drop_last)
+
+
+class GpuBatchLoader:
+    def __init__(self, dataset, batch_size=16, shuffle=False, drop_last=False, gpu_decode=True):
+        if batch_size < 1:
+            raise ValueError("batch_size must be positive")
+        self.dataset, self.batch_size, self.shuffle, self.drop_last, self.gpu_decode = dataset, int(batch_size), bool(shuffle), bool(drop_last), gpu_decode
+        self._encoded = None
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def order(self):
+        """Index order of one epoch (a fresh permutation from torch's default generator when shuffling)."""
+        n = len(self.dataset)
+        idx = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+        return idx[: len(self) * self.batch_size] if self.drop_last else idx
+
+    def __iter__(self):
+        ds = self.dataset
+        dev = ds.processor._dev()
+        idx = self.order()
+        files = [ds.files[i] for i in idx]
+        labels = [ds.labels[i] for i in idx]
+        enc = None
+        if self.gpu_decode:
             from .files import EncodedPaths
-            self._encoded = EncodedPaths(self.files)          # the file list as the native reader takes it, converted once
-        for s in range(0, len(self.files), batch_size):
-            paths = self.files[s:s + batch_size]
-            if gpu_decode:
-                pcm_dev, ok = self.processor.load_clips_gpu(self._encoded, normalize=True, lo=s, hi=min(len(self.files), s + batch_size))
+            if not self.shuffle:
+                if self._encoded is None:
+                    self._encoded = EncodedPaths(files)       # the file list as the native reader takes it, converted once
+                enc = self._encoded
             else:
-                pcm, ok = self.processor.load_clips(paths)
+                enc = EncodedPaths(files)                     # this epoch's order
+        for s in range(0, len(files), self.batch_size):
+            e = min(len(files), s + self.batch_size)
+            if self.gpu_decode:
+                pcm_dev, ok = ds.processor.load_clips_gpu(enc, normalize=True, lo=s, hi=e)
+            else:
+                pcm, ok = ds.processor.load_clips(files[s:e])
                 pcm_dev = torch.from_numpy(pcm).to(dev)
             # both loaders already peak-normalised each file before the crop/pad, as the reference does (:131-133)
-            if self.augment:
-                pcm_dev = self.processor.augment_batch(pcm_dev)          # process_audio_file :134-135
-            data = self.processor.mel_batch(pcm_dev, normalize=False)
+            if ds.augment:
+                pcm_dev = ds.processor.augment_batch(pcm_dev)          # process_audio_file :134-135
+            data = ds.processor.mel_batch(pcm_dev, normalize=False)
             if not ok.all():
-                self.unreadable += int((~ok).sum())
+                ds.unreadable += int((~ok).sum())
                 print(f"WakewordDataset: {int((~ok).sum())} unreadable file(s) in this batch served as zeros "
-                      f"({self.unreadable} so far), e.g. {paths[int(np.argmin(ok))]}")
+                      f"({ds.unreadable} so far), e.g. {files[s + int(np.argmin(ok))]}")
                 data[torch.from_numpy(~ok).to(dev)] = 0.0
-            target = torch.tensor(self.labels[s:s + batch_size], dtype=torch.long, device=dev).unsqueeze(1)
+            target = torch.tensor(labels[s:e], dtype=torch.long, device=dev).unsqueeze(1)
             yield data, target
