@@ -218,6 +218,16 @@ def test_shuffling_loader_is_the_dataloader_line_without_workers(dev, tmp_path):
         orders.append(seen)
     assert orders[0] != orders[1] and orders[0] != list(range(n))
     assert [int(t) for _, tg in ds.loader(16) for t in tg[:, 0]] == ds.labels           # unshuffled: file order
+    # a file too long for the staging buffer in the middle of an epoch: the loader regrows the reader and goes on from that batch
+    long = os.path.join(tmp_path, "long.wav")
+    _write_wav16(long, np.tile(pkg.synth.make_clip(5) * 0.3, 400))                        # 400 s = 12.8 MB of samples
+    ds2 = WakewordDataset(paths[:6] + [long] + paths[6:12], [], AudioProcessor(), verbose=False)
+    got = [d for d, _ in ds2.loader(batch_size=4)]
+    assert [g.shape[0] for g in got] == [4, 4, 4, 1] and all(torch.isfinite(g).all() for g in got)
+    flat = torch.cat(got)[:, 0].cpu().numpy()
+    for k, j in enumerate(list(range(6)) + [None] + list(range(6, 12))):
+        if j is not None:
+            assert np.abs(flat[k] - ref[j]).max() <= 1e-4
 
 
 def test_rccl_gather_path_one_rank():

@@ -5,6 +5,7 @@ staging buffer, status codes, capacity handling.  The same code path feeds pinne
 Reference behaviour being replaced: AudioProcessor.load_audio, /root/reference/wakeword_training_script.py:65-71 (one file at a
 time, print + None on failure); the expected header fields come from audio._parse_wav, the package's own host parser.
 """
+import ctypes as C
 import os
 import struct
 
@@ -149,6 +150,43 @@ def test_encoded_paths_window_reads_the_same_files(corpus):
         d, st = rd.read(enc, 1, lo, hi)
         assert [(int(a["n_frames"]), int(a["sample_rate"]), int(b)) for a, b in zip(d, st)] == want[lo:hi]
     rd.close()
+
+
+def test_stream_reads_one_batch_ahead_and_stops_cleanly(tmp_path):
+    """stream(): the helper thread fills the next slot while the consumer holds the current one; every payload arrives in order; breaking
+    out of the generator stops and joins the thread; a reader with two slots is refused."""
+    r = np.random.default_rng(2)
+    paths, payloads = [], []
+    for i in range(130):
+        raw = r.integers(-2 ** 15, 2 ** 15 - 1, 64 + 7 * (i % 31)).astype("<i2").tobytes()
+        p = os.path.join(tmp_path, f"q{i:03d}.wav")
+        with open(p, "wb") as f:
+            f.write(_wav(raw))
+        paths.append(p); payloads.append(raw)
+    rd = files.WavBatchReader(max_clips=32, max_raw_bytes=1 << 18, threads=4, slots=3, host_only=True)
+    seen = 0
+    for slot, ok in rd.stream(paths, 32):
+        stage = rd.staging(slot)                             # still intact: the producer is at most one slot ahead, in another slot
+        descs = np.frombuffer((C.c_char * (len(ok) * files.DESC_DTYPE.itemsize)).from_address(
+            C.addressof(C.cast(_descs_ptr(rd, slot), C.POINTER(nat.ClipDesc)).contents)), dtype=files.DESC_DTYPE, count=len(ok))
+        assert ok.all()
+        for d, raw in zip(descs, payloads[seen:seen + len(ok)]):
+            assert bytes(stage[int(d["byte_offset"]):int(d["byte_offset"]) + len(raw)]) == raw
+        seen += len(ok)
+    assert seen == 130
+    import threading
+    gen = rd.stream(paths, 16)
+    next(gen)
+    gen.close()                                              # consumer walks away after one batch
+    assert not any(t.name == "ww-wav-reader" and t.is_alive() for t in threading.enumerate())
+    with pytest.raises(ValueError):
+        next(files.WavBatchReader(max_clips=32, threads=2, slots=2, host_only=True).stream(paths, 16))
+    rd.close()
+
+
+def _descs_ptr(rd, slot):
+    """The slot's descriptor array (the library hands it out on every read; ask again with an empty batch-preserving call)."""
+    return rd._last_descs[slot]
 
 
 def test_probe_reads_one_header(corpus):

@@ -200,14 +200,21 @@ class AudioProcessor:
         resample to 16 kHz, whole-file peak normalisation, random crop / zero pad to 1 s -- process_audio_file :125-133
         up to the mel call.  `paths`: a list, or a files.EncodedPaths with a window [lo, hi).  Returns (device tensor [B, 16000],
         ok mask); unreadable files give a zero row, ok False."""
-        from .files import EncodedPaths, WavBatchReader
-        dev = self._dev()
+        from .files import EncodedPaths
         hi = len(paths) if hi is None else hi
-        if getattr(self, "_reader", None) is None or self._reader.device != dev:
-            self._reader = WavBatchReader(max_clips=max(64, hi - lo), device=dev)
         if not isinstance(paths, EncodedPaths):
             paths = list(paths)
-        return self._reader.load(paths, normalize, lo=lo, hi=hi)
+        return self.gpu_reader(hi - lo).load(paths, normalize, lo=lo, hi=hi)
+
+    def gpu_reader(self, batch_size: int = 64):
+        """This processor's native batch reader (3 staging slots, sized for `batch_size` files of up to 2 s of 16 kHz PCM-16; it grows on demand)."""
+        from .files import WavBatchReader
+        dev = self._dev()
+        if getattr(self, "_reader", None) is None or self._reader.device != dev:
+            self._reader = WavBatchReader(max_clips=max(64, batch_size), max_raw_bytes=max(64, batch_size) * 65536, slots=3, device=dev)
+        elif self._reader.max_clips < batch_size:
+            self._reader.regrow(batch_size, batch_size * 65536)
+        return self._reader
 
     def load_clips(self, paths, target_length=None):
         """Decode, peak-normalise and crop/pad a list of files on the host, in the reference's order

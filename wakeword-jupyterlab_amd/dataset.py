@@ -98,13 +98,28 @@ class GpuBatchLoader:
                 enc = self._encoded
             else:
                 enc = EncodedPaths(files)                     # this epoch's order
-        for s in range(0, len(files), self.batch_size):
+        def decoded():
+            """(first index, pcm on the device, ok mask) per batch: the native reader one batch ahead (files.WavBatchReader.stream), or the host path."""
+            if not self.gpu_decode:
+                for s in range(0, len(files), self.batch_size):
+                    pcm, ok = ds.processor.load_clips(files[s:s + self.batch_size])
+                    yield s, torch.from_numpy(pcm).to(dev), ok
+                return
+            from . import _native as nat
+            reader = ds.processor.gpu_reader(self.batch_size)
+            s = 0
+            while s < len(files):
+                try:
+                    for pcm_dev, ok in reader.stream(enc, self.batch_size, normalize=True, verbose=False, start=s):
+                        yield s, pcm_dev, ok
+                        s += self.batch_size
+                except nat.NativeError as e:                   # a batch of long files: larger staging, then on from that batch
+                    if e.code != nat.WW_ENOSPACE:
+                        raise
+                    reader.regrow(self.batch_size, int(e.needed * 1.25) + 4096)
+
+        for s, pcm_dev, ok in decoded():
             e = min(len(files), s + self.batch_size)
-            if self.gpu_decode:
-                pcm_dev, ok = ds.processor.load_clips_gpu(enc, normalize=True, lo=s, hi=e)
-            else:
-                pcm, ok = ds.processor.load_clips(files[s:e])
-                pcm_dev = torch.from_numpy(pcm).to(dev)
             # both loaders already peak-normalised each file before the crop/pad, as the reference does (:131-133)
             if ds.augment:
                 pcm_dev = ds.processor.augment_batch(pcm_dev)          # process_audio_file :134-135

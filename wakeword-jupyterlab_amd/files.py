@@ -69,6 +69,7 @@ class WavBatchReader:
         with self._ctx():
             nat.check(nat.lib.ww_wav_reader_create(self.threads, self.slots, self.max_clips, self.max_raw_bytes, int(self.host_only), C.byref(self._h)))
         self._n = [0] * self.slots
+        self._last_descs = [None] * self.slots
         self._next = 0
 
     def _ctx(self):
@@ -119,6 +120,7 @@ class WavBatchReader:
             raise e
         nat.check(rc)
         self._n[slot] = n
+        self._last_descs[slot] = C.cast(descs_p, C.c_void_p)      # where the library keeps this slot's descriptors (tests)
         if n == 0:
             return np.zeros(0, dtype=DESC_DTYPE), status[:0]
         buf = (C.c_char * (n * DESC_DTYPE.itemsize)).from_address(C.addressof(descs_p.contents))
@@ -171,6 +173,65 @@ class WavBatchReader:
             for i in np.nonzero(~ok)[0][:8]:
                 print(f"Error loading {names[lo + i]}: {nat.WAV_STATUS.get(int(status[i]), status[i])}")
         return self.decode(slot, normalize, out), ok
+
+    def stream(self, paths, batch_size: int, normalize: bool = True, verbose: bool = True, start: int = 0):
+        """Generator over `paths` in batches of `batch_size`: yields (device tensor [B, 16000], ok mask) per batch.  A helper thread runs
+        the reader one batch AHEAD (the ctypes call releases the GIL; the crops are drawn there too), the caller's thread only uploads /
+        launches K0 -- the host's file reading then overlaps both the GPU and the caller's own Python work between batches.  Needs a reader
+        with >= 3 slots (one being filled, one waiting, one in flight).  A batch that does not fit the staging buffer raises NativeError
+        (WW_ENOSPACE, `.needed`): size the reader for the largest batch, or `regrow()` it and call stream(..., start=that batch's first index)."""
+        import queue
+        import threading
+        if self.slots < 3:
+            raise ValueError("stream() needs a reader with at least 3 slots")
+        enc = paths if isinstance(paths, EncodedPaths) else EncodedPaths(paths)
+        n = len(enc)
+        if batch_size < 1 or batch_size > self.max_clips:
+            raise ValueError(f"batch_size {batch_size}: the reader was created for 1..{self.max_clips} files per batch")
+        q: queue.Queue = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                for lo in range(start, n, batch_size):
+                    if stop.is_set():
+                        return
+                    hi = min(n, lo + batch_size)
+                    slot = self.next_slot()
+                    descs, status = self.read(enc, slot, lo, hi)
+                    self.draw_crops(descs, status)
+                    q.put((slot, lo, status))
+                q.put(None)
+            except BaseException as e:              # noqa: BLE001  (handed to the consumer)
+                q.put(e)
+
+        t = threading.Thread(target=producer, name="ww-wav-reader", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                slot, lo, status = item
+                ok = status == 1
+                if verbose and not ok.all():
+                    for i in np.nonzero(~ok)[0][:8]:
+                        print(f"Error loading {enc.paths[lo + i]}: {nat.WAV_STATUS.get(int(status[i]), status[i])}")
+                yield (slot if self.host_only else self.decode(slot, normalize)), ok     # host-only readers (tests) hand out the slot number
+        finally:
+            stop.set()
+            while t.is_alive():                      # drain so that a producer blocked on put() can finish
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            t.join()
+
+    def regrow(self, max_clips: int, max_raw_bytes: int) -> None:
+        """Re-create the reader with larger staging (synchronises the device first: nothing may still read the old buffers)."""
+        self._regrow(max(max_clips, self.max_clips), max(max_raw_bytes, self.max_raw_bytes))
 
     def _regrow(self, max_clips: int, max_raw_bytes: int) -> None:
         if not self.host_only:
