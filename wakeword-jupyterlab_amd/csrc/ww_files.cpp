@@ -14,7 +14,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -372,7 +374,12 @@ int ww_read_wav_batch_host(ww_wav_reader* r, const char* const* paths, int64_t n
     }
     Job j;
     j.paths = paths; j.n = n; j.slot = &s; j.status = status_host; j.capacity = r->max_raw;
+    static const bool trace = getenv("WW_READER_TRACE") != nullptr;     // diagnostics: time of the threaded part of every call, on stderr
+    const auto t0 = std::chrono::steady_clock::now();
     run_job(r, &j);
+    if (trace)
+        std::fprintf(stderr, "[ww reader] %lld files, %d threads: %.3f ms\n", (long long)n, r->n_threads,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     s.n = n;
     const int64_t need = j.cursor.load();                      // every usable file reserved its aligned size, whether it fitted or not
     s.raw_bytes = need < r->max_raw ? need : r->max_raw;
