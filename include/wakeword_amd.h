@@ -171,7 +171,8 @@ WW_API int ww_decode_resample(const uint8_t* raw_dev, const ww_clip_desc* descs_
  *                           previous upload has left the staging buffer.
  *   ww_wav_batch_decode     H2D copy of the slot on the reader's copy stream, then K0 (ww_decode_resample) on `stream`
  *                           behind it: pcm_out_dev [n][16000].  Asynchronous; the next ww_read_wav_batch_host on ANOTHER
- *                           slot overlaps with it.  The upload of a slot waits for the K0 that last read its device twin. */
+ *                           slot overlaps with it.  The upload of a slot waits for the K0 that last read its device twin.
+ * A reader serves ONE caller at a time (its thread pool runs one batch); use one reader per consumer thread. */
 #define WW_WAV_EOPEN (-1)    /* cannot open */
 #define WW_WAV_ENOTRIFF (-2) /* not a RIFF/WAVE file */
 #define WW_WAV_ECHUNK (-3)   /* fmt or data chunk missing / truncated */

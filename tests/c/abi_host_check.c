@@ -46,6 +46,42 @@ int main(int argc, char** argv) {
     CHECK(ww_logmel_f32(NULL, 4, 16000, 16000, 1, NULL, NULL) == WW_EINVAL);
     CHECK(ww_logmel_f32((const float*)16, 4, 16000, 20000, 1, (float*)16, NULL) == WW_EINVAL);
     CHECK(ww_set_conv_math(7) == WW_EINVAL && ww_get_conv_math() == WW_CONV_MATH_F16X3);
+    CHECK(ww_train_workspace_bytes(64, 2, WW_TRAIN_MATH_F16X3) < ww_train_workspace_bytes(64, 2, WW_TRAIN_MATH_F32));
+    CHECK(ww_set_conv_math_thread(WW_CONV_MATH_F32) == WW_OK && ww_get_conv_math() == WW_CONV_MATH_F32);
+    CHECK(ww_set_conv_math_thread(WW_MATH_INHERIT) == WW_OK && ww_get_conv_math() == WW_CONV_MATH_F16X3);
+    /* the batch WAV reader from C, host-only mode (no GPU): one file written here, read back through the thread pool */
+    {
+        unsigned char hdr[44] = {'R', 'I', 'F', 'F', 0, 0, 0, 0, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 1, 0,
+                                 0x80, 0x3e, 0, 0, 0, 0x7d, 0, 0, 2, 0, 16, 0, 'd', 'a', 't', 'a', 0, 0, 0, 0};
+        const char* path = argc > 2 ? argv[2] : "/tmp/ww_abi_host_check.wav";
+        const char* paths[2];
+        short samples[100];
+        ww_wav_reader* rd = NULL;
+        ww_clip_desc* descs = NULL;
+        ww_clip_desc probe;
+        const uint8_t* stage = NULL;
+        int8_t status[2];
+        int64_t need = 0, staged = 0;
+        FILE* f;
+        for (k = 0; k < 100; ++k) samples[k] = (short)(37 * k - 1000);
+        hdr[4] = (unsigned char)(36 + 200); hdr[40] = 200;
+        f = fopen(path, "wb");
+        CHECK(f != NULL);
+        CHECK(fwrite(hdr, 1, 44, f) == 44 && fwrite(samples, 2, 100, f) == 100);
+        fclose(f);
+        paths[0] = path; paths[1] = "/nonexistent/ww.wav";
+        CHECK(ww_wav_probe_host(path, &probe) == 1 && probe.n_frames == 100 && probe.sample_rate == 16000 && probe.byte_offset == 44);
+        CHECK(ww_wav_reader_create(2, 2, 8, 4096, WW_READER_HOST_ONLY, &rd) == WW_OK);
+        CHECK(ww_read_wav_batch_host(rd, paths, 2, 1, &descs, status, &need) == WW_OK);
+        CHECK(status[0] == 1 && status[1] == WW_WAV_EOPEN && need == 208 && descs[0].n_frames == 100 && descs[0].format == WW_FMT_S16);
+        CHECK(descs[1].n_frames == 0 && descs[0].up == 1 && descs[0].down == 1);
+        CHECK(ww_wav_reader_staging(rd, 1, &stage, &staged) == WW_OK && staged == 208);
+        CHECK(memcmp(stage + descs[0].byte_offset, samples, 200) == 0);
+        CHECK(ww_wav_batch_decode(rd, 1, 1, (float*)16, NULL) == WW_EUNSUPPORTED);       /* host-only: nothing to decode on */
+        CHECK(ww_wav_reader_create(2, 2, 8, 64, WW_READER_HOST_ONLY, NULL) == WW_EINVAL);
+        CHECK(ww_wav_reader_destroy(rd) == WW_OK);
+        remove(path);
+    }
     if (!have_gpu) {
         /* no CPU fallback: every launch fails loudly without a gfx950 device */
         CHECK(ww_init() == WW_ENODEVICE);

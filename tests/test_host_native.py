@@ -259,5 +259,5 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
                     "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.dirname(torch.__file__) + "/lib:" + env.get("LD_LIBRARY_PATH", "")
-    r = subprocess.run([exe] + (["gpu"] if HAS_GPU else []), capture_output=True, text=True, env=env, timeout=120)
+    r = subprocess.run([exe, "gpu" if HAS_GPU else "cpu", os.path.join(tmp_path, "abi_check.wav")], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0 and "abi_host_check OK" in r.stdout, r.stderr

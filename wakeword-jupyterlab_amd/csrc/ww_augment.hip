@@ -315,12 +315,20 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
             int i_max = (kKbLen - offset) / index_step;
             i_max = i_max < n + 1 ? i_max : n + 1;
             {
+#ifdef WW_ABL_RS_SAMEROW          // timing-only ablation: every lane of a wave reads the same table rows (no bank conflicts; results are garbage)
+                const float* r0 = P + __builtin_amdgcn_readfirstlane(offset) * R;
+#else
                 const float* r0 = P + offset * R;
+#endif
                 const float* r1 = r0 + R;
                 int i = 0;
                 for (; i + 4 <= i_max; i += 4) {
                     const float4 t0 = *reinterpret_cast<const float4*>(r0 + i), t1 = *reinterpret_cast<const float4*>(r1 + i);
+#ifdef WW_ABL_RS_NOY              // timing-only ablation: no sample loads
+                    const f4u yy = {eta, t0.x, t1.y, 1.0f};
+#else
                     const f4u yy = *reinterpret_cast<const f4u*>(y + n - i - 3);          // y[n-i-3 .. n-i]
+#endif
                     accl = fmaf(fmaf(eta, t1.x - t0.x, t0.x), yy.w, accl);
                     accl = fmaf(fmaf(eta, t1.y - t0.y, t0.y), yy.z, accl);
                     accl = fmaf(fmaf(eta, t1.z - t0.z, t0.z), yy.y, accl);
@@ -338,12 +346,20 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
             int k_max = (kKbLen - offset) / index_step;
             k_max = k_max < n_orig - n - 1 ? k_max : n_orig - n - 1;
             {
+#ifdef WW_ABL_RS_SAMEROW
+                const float* r0 = P + __builtin_amdgcn_readfirstlane(offset) * R;
+#else
                 const float* r0 = P + offset * R;
+#endif
                 const float* r1 = r0 + R;
                 int k = 0;
                 for (; k + 4 <= k_max; k += 4) {
                     const float4 t0 = *reinterpret_cast<const float4*>(r0 + k), t1 = *reinterpret_cast<const float4*>(r1 + k);
+#ifdef WW_ABL_RS_NOY
+                    const f4u yy = {eta, t0.x, t1.y, 1.0f};
+#else
                     const f4u yy = *reinterpret_cast<const f4u*>(y + n + 1 + k);          // y[n+1+k .. n+4+k]
+#endif
                     accr = fmaf(fmaf(eta, t1.x - t0.x, t0.x), yy.x, accr);
                     accr = fmaf(fmaf(eta, t1.y - t0.y, t0.y), yy.y, accr);
                     accr = fmaf(fmaf(eta, t1.z - t0.z, t0.z), yy.z, accr);
