@@ -7,6 +7,8 @@ for L in "$@"; do
 import csv,glob
 for f in glob.glob("gpurun_out/ab_aug/$(basename $L .so)/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        if "resample" in r["Name"]: print("$(basename $L)", "resample_kernel", round(float(r["AverageNs"])/1e6,4), "ms")
+        nm = r["Name"].split("(")[0].replace("ww::", "")
+        if nm.split("<")[0].endswith(("resample_kernel", "stft_kernel", "pv_kernel", "istft_kernel", "stft_pv_kernel", "noise_kernel", "roll_kernel")):
+            print("$(basename $L)", nm, r["Calls"], round(float(r["AverageNs"])/1e6,4), "ms")
 PY
 done

@@ -32,6 +32,11 @@ constexpr int kAugFrames = kFrames;                 // STFT frames of a 16000-sa
 constexpr int kAugMaxOut = 46;                      // phase-vocoder output steps: ceil(32 / rate), rate >= 32/46
 constexpr int kAugYStride = 25600;                  // stretched-clip scratch row
 constexpr int kSpec = kBins;                        // 1025 complex bins per spectrum row
+#ifdef WW_AUG_SPLIT_STFT_PV                         // timing-only build: stft_kernel and pv_kernel as two launches with the columns in HBM
+constexpr int kAugDFrames = kAugFrames;
+#else
+constexpr int kAugDFrames = 0;                      // the STFT columns live in LDS (stft_pv_kernel): no spectrum buffer in the workspace
+#endif
 
 struct AugDev {            // one per clip, derived on the host from ww_augment_plan
     int32_t shift;         // np.roll shift reduced to [0, L)
@@ -105,9 +110,20 @@ __device__ __forceinline__ float2 pv_col(const float2* __restrict__ Dc, int f, i
 // atan2 for the vocoder: a = min/max in [0, 1], atan(a) = a P(a^2) (degree 8 in a^2, |err| <= 1.2e-7 in float32 evaluation -- the size of
 // libm's own last-place error at these magnitudes), octant and quadrant folded back; signed zeros and (0, 0) as atan2f has them.
 __device__ __forceinline__ float pv_atan2(float y, float x) {
+#ifdef WW_ABL_PV_LIBM_ATAN
+    return atan2f(y, x);
+#endif
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+#ifndef WW_ABL_PV_PRECISE_DIV
+    // min / max by v_rcp_f32 (1 ulp; the polynomial's own error is of that size).  The hardware reciprocal takes denormals for zero, so
+    // tiny pairs are scaled up first (exact, the ratio is unchanged)
+    const float sc = mx < 5.4210109e-20f ? 1.8446744e19f : 1.0f;                      // 2^-64, 2^64
+    mx *= sc; mn *= sc;
+    const float a = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+#else
     const float a = mx > 0.f ? mn / mx : 0.f;
+#endif
     const float q = a * a;
     float p = 2.399661113e-03f;
     p = fmaf(p, q, -1.415910292e-02f);
@@ -128,7 +144,31 @@ __device__ __forceinline__ float pv_atan2(float y, float x) {
 // its large-argument reduction path there (round 2: the bulk of this kernel's time).  Here the turn count acc / 2 pi is formed in double, its
 // fraction goes to the hardware's v_sin_f32 / v_cos_f32 (arguments in revolutions; absolute error ~1e-6, five hundred times under the tests' bound
 // on the output samples).
+// |c| by v_sqrt_f32 (1 ulp) instead of the correctly rounded expansion
+__device__ __forceinline__ float pv_abs(float2 c) {
+#ifndef WW_ABL_PV_PRECISE_DIV
+    return __builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y));
+#else
+    return sqrtf(fmaf(c.x, c.x, c.y * c.y));
+#endif
+}
+
+// round(dphase / 2 pi) with the quotient formed by the reciprocal: differs from the division only when the quotient is within an ulp of a
+// half-integer, where either neighbour wraps the phase to the same angle (the accumulator then differs by its own rounding of +-2 pi)
+__device__ __forceinline__ double pv_wrap(double dphase) {
+    const double two_pi = 6.283185307179586476925286766559;
+#ifndef WW_ABL_PV_PRECISE_DIV
+    return dphase - two_pi * __builtin_rint(dphase * 0.15915494309189533576888);
+#else
+    return dphase - two_pi * __builtin_rint(dphase / two_pi);
+#endif
+}
+
 __device__ __forceinline__ void pv_sincos(float acc, float& sn, float& cs) {
+#ifdef WW_ABL_PV_LIBM_SINCOS
+    sincosf(acc, &sn, &cs);
+    return;
+#endif
     const double turns = double(acc) * 0.15915494309189533576888;       // 1 / (2 pi)
     const float fr = float(turns - __builtin_rint(turns));                // [-0.5, 0.5]
     sn = __builtin_amdgcn_sinf(fr);
@@ -159,9 +199,9 @@ __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, c
             const double alpha = step - double(i0);
             if (i0 != have) {
                 if (i0 == have + 1) { m0 = m1; a0 = a1; }
-                else { const float2 c0 = pv_col(Dc, i0, k); m0 = sqrtf(fmaf(c0.x, c0.x, c0.y * c0.y)); a0 = pv_atan2(c0.y, c0.x); }
+                else { const float2 c0 = pv_col(Dc, i0, k); m0 = pv_abs(c0); a0 = pv_atan2(c0.y, c0.x); }
                 const float2 c1 = pv_col(Dc, i0 + 1, k);
-                m1 = sqrtf(fmaf(c1.x, c1.x, c1.y * c1.y));       // |c|: STFT magnitudes of unit-peak clips stay far inside float range
+                m1 = pv_abs(c1);                                 // |c|: STFT magnitudes of unit-peak clips stay far inside float range
                 a1 = pv_atan2(c1.y, c1.x);
                 have = i0;
             }
@@ -171,9 +211,117 @@ __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, c
             Sc[int64_t(t) * kSpec + k] = make_float2(cs * mag, sn * mag);
             const float da = a1 - a0;
             double dphase = double(da) - phi;
-            dphase = dphase - two_pi * rint(dphase / two_pi);
+            dphase = pv_wrap(dphase);
             acc = float(double(acc) + (phi + dphase));
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stft_kernel + pv_kernel in one pass over the clip: the STFT columns never leave the CU.  Four frames per round (one per wave) are
+// transformed into a ring of eight LDS slabs and split IN PLACE into their spectrum column (a lane reads Z[k], Z[1024-k] and writes
+// D[k], D[1024-k] back to the same two slots; D[1024] takes the slab's spare slot), then every thread advances its bins' vocoder state
+// over the output steps whose two columns are there.  A step reads columns i0, i0 + 1 with i0 non-decreasing, so round r + 1 may
+// overwrite the columns of round r - 1 (two barriers per round).  Same arithmetic as the two kernels, bit-identical S.
+constexpr int kStftPvLds = 8 * fft::kSlabFloats * int(sizeof(float));                    // 65,664 B: two workgroups per CU
+
+__global__ __launch_bounds__(256) void stft_pv_kernel(const float* __restrict__ x, const AugDev* __restrict__ plan, int which,
+                                                      const LogmelTables* __restrict__ tb, float2* __restrict__ S) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int clip = blockIdx.x, tid = threadIdx.x;
+    const int n_out = which == 0 ? plan[clip].p_out : plan[clip].s_out;
+    if (n_out == 0) return;
+    const double rate = which == 0 ? plan[clip].p_rate : plan[clip].s_rate;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* xc = x + int64_t(clip) * kClip;
+    const float4* win4 = reinterpret_cast<const float4*>(&tb->window[0]);
+    float2* Sc = S + int64_t(clip) * kAugMaxOut * kSpec;
+    constexpr int kB = 5;                                        // bins tid + 256 b; b = 4 is bin 1024 (thread 0 only)
+    float acc[kB], m0[kB], a0[kB], m1[kB], a1[kB];
+#pragma unroll
+    for (int b = 0; b < kB; ++b) { acc[b] = 0.f; m0[b] = 0.f; a0[b] = 0.f; m1[b] = 0.f; a1[b] = 0.f; }
+    int have = -2, t = 0;
+    for (int r = 0; r < kAugFrames / 4; ++r) {
+        {
+            const int frame = 4 * r + wave;
+            float* slab = lds + (frame & 7) * fft::kSlabFloats;
+            float2* slab2 = reinterpret_cast<float2*>(slab);
+            float2 za[8], zb[8];
+            const int base = frame * kHop - kNfft / 2 + 4 * lane;
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int idx = base + 256 * n1;
+                const float4 s = (idx >= 0 && idx < kClip) ? *reinterpret_cast<const float4*>(xc + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 w = win4[64 * n1 + lane];
+                za[n1] = make_float2(s.x * w.x, s.y * w.y);
+                zb[n1] = make_float2(s.z * w.z, s.w * w.w);
+            }
+            fft::wave_fft1024(za, zb, slab, tb, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = lane + 64 * j;                     // 0..511
+                const int pa = fft::zpos(k), pb = fft::zpos((1024 - k) & 1023);
+                const float2 a = slab2[pa], b = slab2[pb];
+                const float2 tw = tb->twr[k];
+                const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+                const float2 o = make_float2(0.5f * (a.y + b.y), 0.5f * (b.x - a.x));
+                const float2 tt = fft::cmul(o, tw);
+                slab2[pa] = make_float2(e.x + tt.x, e.y + tt.y);
+                slab2[k == 0 ? 1024 : pb] = make_float2(e.x - tt.x, -(e.y - tt.y));
+            }
+            if (lane == 0) { const int pz = fft::zpos(512); const float2 z = slab2[pz]; slab2[pz] = make_float2(z.x, -z.y); }
+        }
+        __syncthreads();                                         // columns <= 4r + 3 are in their slabs
+        {
+#pragma clang fp contract(off)
+            const double two_pi = 6.283185307179586476925286766559;
+            if (r == 0) {
+                const float2* c = reinterpret_cast<const float2*>(lds);
+#pragma unroll
+                for (int b = 0; b < kB; ++b) {
+                    const int k = tid + 256 * b;
+                    if (k < kSpec) { const float2 d0 = c[fft::zpos(k)]; acc[b] = pv_atan2(d0.y, d0.x); }
+                }
+            }
+            const int last = 4 * r + 3;
+            for (; t < n_out; ++t) {
+                const double step = double(t) * rate;
+                const int i0 = int(step);
+                if ((i0 + 1 < kAugFrames ? i0 + 1 : kAugFrames - 1) > last) break;      // this step's columns come with a later round
+                const double alpha = step - double(i0);
+                const bool fresh0 = i0 != have && i0 != have + 1, fresh1 = i0 != have;
+                const float2* c0 = reinterpret_cast<const float2*>(lds + (i0 & 7) * fft::kSlabFloats);
+                const float2* c1 = reinterpret_cast<const float2*>(lds + ((i0 + 1) & 7) * fft::kSlabFloats);
+#pragma unroll
+                for (int b = 0; b < kB; ++b) {
+                    const int k = tid + 256 * b;
+                    if (k < kSpec) {
+                        const double phi = double(k) * two_pi * 0.25;
+                        if (fresh1) {
+                            if (!fresh0) { m0[b] = m1[b]; a0[b] = a1[b]; }
+                            else {
+                                const float2 v = i0 < kAugFrames ? c0[fft::zpos(k)] : make_float2(0.f, 0.f);
+                                m0[b] = pv_abs(v);
+                                a0[b] = pv_atan2(v.y, v.x);
+                            }
+                            const float2 v = i0 + 1 < kAugFrames ? c1[fft::zpos(k)] : make_float2(0.f, 0.f);
+                            m1[b] = pv_abs(v);
+                            a1[b] = pv_atan2(v.y, v.x);
+                        }
+                        const float mag = float(1.0 - alpha) * m0[b] + float(alpha) * m1[b];
+                        float sn, cs;
+                        pv_sincos(acc[b], sn, cs);
+                        Sc[int64_t(t) * kSpec + k] = make_float2(cs * mag, sn * mag);
+                        const float da = a1[b] - a0[b];
+                        double dphase = double(da) - phi;
+                        dphase = pv_wrap(dphase);
+                        acc[b] = float(double(acc[b]) + (phi + dphase));
+                    }
+                }
+                have = i0;
+            }
+        }
+        __syncthreads();                                         // the next round overwrites the columns of round r - 1
     }
 }
 
@@ -418,7 +566,7 @@ __global__ __launch_bounds__(256) void noise_kernel(const float* __restrict__ in
 static int64_t up256(int64_t b) { return (b + 255) & ~int64_t(255); }
 
 int64_t augment_workspace_bytes(int64_t n) {
-    return up256(n * int64_t(sizeof(AugDev))) + 2 * up256(n * int64_t(kClip) * 4) + up256(n * int64_t(kAugFrames) * kSpec * 8) +
+    return up256(n * int64_t(sizeof(AugDev))) + 2 * up256(n * int64_t(kClip) * 4) + up256(n * int64_t(kAugDFrames) * kSpec * 8) +
            up256(n * int64_t(kAugMaxOut) * kSpec * 8) + up256(n * int64_t(kAugYStride) * 4);
 }
 
@@ -492,7 +640,7 @@ int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const vo
     w += up256(n * int64_t(sizeof(AugDev)));                        // (the slot ww_augment_f32 copies its records into)
     float* bufA = reinterpret_cast<float*>(w); w += up256(n * int64_t(kClip) * 4);
     float* bufB = reinterpret_cast<float*>(w); w += up256(n * int64_t(kClip) * 4);
-    float2* D = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugFrames) * kSpec * 8);
+    [[maybe_unused]] float2* D = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugDFrames) * kSpec * 8);
     float2* S = reinterpret_cast<float2*>(w); w += up256(n * int64_t(kAugMaxOut) * kSpec * 8);
     float* Y = reinterpret_cast<float*>(w);
     {
@@ -503,6 +651,7 @@ int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const vo
         WW_HIP(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !attr[dev]) {
             WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(istft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIstftLds));
+            WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_pv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kStftPvLds));
             WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kResampleLds));
             attr[dev] = true;
         }
@@ -512,16 +661,24 @@ int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const vo
     float* cur = bufA;
     float* other = bufB;
     if (any_pitch) {
+#ifdef WW_AUG_SPLIT_STFT_PV
         hipLaunchKernelGGL(stft_kernel, dim3(unsigned(n)), dim3(256), 0, stream, cur, plan, 0, tb, D);
         hipLaunchKernelGGL(pv_kernel, dim3(unsigned(n)), dim3(256), 0, stream, D, plan, 0, S);
+#else
+        hipLaunchKernelGGL(stft_pv_kernel, dim3(unsigned(n)), dim3(256), kStftPvLds, stream, cur, plan, 0, tb, S);
+#endif
         hipLaunchKernelGGL(istft_kernel, dim3(unsigned(n)), dim3(256), kIstftLds, stream, S, plan, 0, tb,
                            static_cast<const float*>(nullptr), Y, int64_t(kAugYStride));
         hipLaunchKernelGGL(resample_kernel, dim3(unsigned(n)), dim3(1024), kResampleLds, stream, Y, plan, tb, cur, other);
         float* t = cur; cur = other; other = t;
     }
     if (any_stretch) {
+#ifdef WW_AUG_SPLIT_STFT_PV
         hipLaunchKernelGGL(stft_kernel, dim3(unsigned(n)), dim3(256), 0, stream, cur, plan, 1, tb, D);
         hipLaunchKernelGGL(pv_kernel, dim3(unsigned(n)), dim3(256), 0, stream, D, plan, 1, S);
+#else
+        hipLaunchKernelGGL(stft_pv_kernel, dim3(unsigned(n)), dim3(256), kStftPvLds, stream, cur, plan, 1, tb, S);
+#endif
         hipLaunchKernelGGL(istft_kernel, dim3(unsigned(n)), dim3(256), kIstftLds, stream, S, plan, 1, tb, cur, other, int64_t(kClip));
         float* t = cur; cur = other; other = t;
     }
