@@ -451,72 +451,73 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
     const double inv = 1.0 / ratio;
     for (int t = tid; t < kClip; t += 1024) {
         // positions and table fractions in float64 (t / ratio needs ~15 integer + 9 fraction bits); the ~140 products per
-        // output are float32 FMAs in two independent chains (left wing, right wing), each in tap order
+        // output are float32 FMAs in two independent chains (left wing, right wing), each in tap order.  The two wings advance in
+        // lock-step while both have taps left (round 3: twice the loads in flight per wave -- the kernel waits on its table and sample
+        // reads, four waves per SIMD being all the LDS-resident table leaves room for)
         float accl = 0.f, accr = 0.f;
         const double time_register = double(t) * inv;
         const int n = int(time_register);
         if (t < n_res && n < n_orig) {
-            double frac = scale * (time_register - double(n));
-            double index_frac = frac * kKbTable;
-            int offset = int(index_frac);
-            float eta = float(index_frac - double(offset));
-            int i_max = (kKbLen - offset) / index_step;
+            const double frac_l = scale * (time_register - double(n));
+            const double if_l = frac_l * kKbTable;
+            const int off_l = int(if_l);
+            const float eta_l = float(if_l - double(off_l));
+            int i_max = (kKbLen - off_l) / index_step;
             i_max = i_max < n + 1 ? i_max : n + 1;
-            {
-#ifdef WW_ABL_RS_SAMEROW          // timing-only ablation: every lane of a wave reads the same table rows (no bank conflicts; results are garbage)
-                const float* r0 = P + __builtin_amdgcn_readfirstlane(offset) * R;
-#else
-                const float* r0 = P + offset * R;
-#endif
-                const float* r1 = r0 + R;
-                int i = 0;
-                for (; i + 4 <= i_max; i += 4) {
-                    const float4 t0 = *reinterpret_cast<const float4*>(r0 + i), t1 = *reinterpret_cast<const float4*>(r1 + i);
-#ifdef WW_ABL_RS_NOY              // timing-only ablation: no sample loads
-                    const f4u yy = {eta, t0.x, t1.y, 1.0f};
-#else
-                    const f4u yy = *reinterpret_cast<const f4u*>(y + n - i - 3);          // y[n-i-3 .. n-i]
-#endif
-                    accl = fmaf(fmaf(eta, t1.x - t0.x, t0.x), yy.w, accl);
-                    accl = fmaf(fmaf(eta, t1.y - t0.y, t0.y), yy.z, accl);
-                    accl = fmaf(fmaf(eta, t1.z - t0.z, t0.z), yy.y, accl);
-                    accl = fmaf(fmaf(eta, t1.w - t0.w, t0.w), yy.x, accl);
-                }
-                for (; i < i_max; ++i) {
-                    const float w0 = r0[i], w1 = r1[i];
-                    accl = fmaf(fmaf(eta, w1 - w0, w0), y[n - i], accl);
-                }
-            }
-            frac = scale - frac;
-            index_frac = frac * kKbTable;
-            offset = int(index_frac);
-            eta = float(index_frac - double(offset));
-            int k_max = (kKbLen - offset) / index_step;
+            const double frac_r = scale - frac_l;
+            const double if_r = frac_r * kKbTable;
+            const int off_r = int(if_r);
+            const float eta_r = float(if_r - double(off_r));
+            int k_max = (kKbLen - off_r) / index_step;
             k_max = k_max < n_orig - n - 1 ? k_max : n_orig - n - 1;
-            {
-#ifdef WW_ABL_RS_SAMEROW
-                const float* r0 = P + __builtin_amdgcn_readfirstlane(offset) * R;
+#ifdef WW_ABL_RS_SAMEROW          // timing-only ablation: every lane of a wave reads the same table rows (broadcast reads; results are garbage)
+            const float* l0 = P + __builtin_amdgcn_readfirstlane(off_l) * R;
+            const float* r0 = P + __builtin_amdgcn_readfirstlane(off_r) * R;
 #else
-                const float* r0 = P + offset * R;
+            const float* l0 = P + off_l * R;
+            const float* r0 = P + off_r * R;
 #endif
-                const float* r1 = r0 + R;
-                int k = 0;
-                for (; k + 4 <= k_max; k += 4) {
-                    const float4 t0 = *reinterpret_cast<const float4*>(r0 + k), t1 = *reinterpret_cast<const float4*>(r1 + k);
+            const float* l1 = l0 + R;
+            const float* r1 = r0 + R;
+            auto left4 = [&](int i) {
+                const float4 t0 = *reinterpret_cast<const float4*>(l0 + i), t1 = *reinterpret_cast<const float4*>(l1 + i);
+#ifdef WW_ABL_RS_NOY              // timing-only ablation: no sample loads
+                const f4u yy = {eta_l, t0.x, t1.y, 1.0f};
+#else
+                const f4u yy = *reinterpret_cast<const f4u*>(y + n - i - 3);              // y[n-i-3 .. n-i]
+#endif
+                accl = fmaf(fmaf(eta_l, t1.x - t0.x, t0.x), yy.w, accl);
+                accl = fmaf(fmaf(eta_l, t1.y - t0.y, t0.y), yy.z, accl);
+                accl = fmaf(fmaf(eta_l, t1.z - t0.z, t0.z), yy.y, accl);
+                accl = fmaf(fmaf(eta_l, t1.w - t0.w, t0.w), yy.x, accl);
+            };
+            auto right4 = [&](int k) {
+                const float4 t0 = *reinterpret_cast<const float4*>(r0 + k), t1 = *reinterpret_cast<const float4*>(r1 + k);
 #ifdef WW_ABL_RS_NOY
-                    const f4u yy = {eta, t0.x, t1.y, 1.0f};
+                const f4u yy = {eta_r, t0.x, t1.y, 1.0f};
 #else
-                    const f4u yy = *reinterpret_cast<const f4u*>(y + n + 1 + k);          // y[n+1+k .. n+4+k]
+                const f4u yy = *reinterpret_cast<const f4u*>(y + n + 1 + k);              // y[n+1+k .. n+4+k]
 #endif
-                    accr = fmaf(fmaf(eta, t1.x - t0.x, t0.x), yy.x, accr);
-                    accr = fmaf(fmaf(eta, t1.y - t0.y, t0.y), yy.y, accr);
-                    accr = fmaf(fmaf(eta, t1.z - t0.z, t0.z), yy.z, accr);
-                    accr = fmaf(fmaf(eta, t1.w - t0.w, t0.w), yy.w, accr);
-                }
-                for (; k < k_max; ++k) {
-                    const float w0 = r0[k], w1 = r1[k];
-                    accr = fmaf(fmaf(eta, w1 - w0, w0), y[n + k + 1], accr);
-                }
+                accr = fmaf(fmaf(eta_r, t1.x - t0.x, t0.x), yy.x, accr);
+                accr = fmaf(fmaf(eta_r, t1.y - t0.y, t0.y), yy.y, accr);
+                accr = fmaf(fmaf(eta_r, t1.z - t0.z, t0.z), yy.z, accr);
+                accr = fmaf(fmaf(eta_r, t1.w - t0.w, t0.w), yy.w, accr);
+            };
+            const int both = (i_max < k_max ? i_max : k_max) & ~3;
+            int i = 0;
+#ifndef WW_ABL_RS_SEQUENTIAL
+            for (; i < both; i += 4) { left4(i); right4(i); }
+#endif
+            int k = i;
+            for (; i + 4 <= i_max; i += 4) left4(i);
+            for (; i < i_max; ++i) {
+                const float w0 = l0[i], w1 = l1[i];
+                accl = fmaf(fmaf(eta_l, w1 - w0, w0), y[n - i], accl);
+            }
+            for (; k + 4 <= k_max; k += 4) right4(k);
+            for (; k < k_max; ++k) {
+                const float w0 = r0[k], w1 = r1[k];
+                accr = fmaf(fmaf(eta_r, w1 - w0, w0), y[n + k + 1], accr);
             }
         }
         float acc = accl + accr;
