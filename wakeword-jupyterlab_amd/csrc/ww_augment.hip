@@ -440,15 +440,31 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
     int R = (cnt + 3) & ~3;
     if (((R >> 2) & 1) == 0) R += 4;                              // an odd number of 16-byte slots per row spreads the rows over the banks
     // index kKbLen is the pad np.diff(win) gets (the last value again): tab[kKbLen] = tab[kKbLen - 1]
+#ifdef WW_ABL_RS_OLDBUILD
     for (int i = 0; i < R; ++i)
         for (int ph = tid; ph < index_step + 2; ph += 1024) {
             const int j = ph + i * index_step;
             P[ph * R + i] = (i < cnt && j <= kKbLen) ? tb->kaiser_best[j < kKbLen ? j : kKbLen - 1] : 0.f;
         }
+#else
+    {   // every thread takes (step + 2) * R / 1024 entries, phase-fastest (coalesced table reads), four loads in flight
+        const int rows = index_step + 2, total = rows * R;
+#pragma unroll 4
+        for (int e = tid; e < total; e += 1024) {
+            const int i = e / rows, ph = e - i * rows;
+            const int j = ph + i * index_step;
+            P[ph * R + i] = (i < cnt && j <= kKbLen) ? tb->kaiser_best[j < kKbLen ? j : kKbLen - 1] : 0.f;
+        }
+    }
+#endif
     __syncthreads();
     const int n_orig = plan[clip].p_len, n_res = plan[clip].p_res;
     const float* y = Y + int64_t(clip) * kAugYStride;
     const double inv = 1.0 / ratio;
+#ifdef WW_ABL_RS_NOMAIN               // timing-only ablation: the table build alone
+    for (int t = tid; t < kClip; t += 1024) o[t] = P[t];
+    return;
+#endif
     for (int t = tid; t < kClip; t += 1024) {
         // positions and table fractions in float64 (t / ratio needs ~15 integer + 9 fraction bits); the ~140 products per
         // output are float32 FMAs in two independent chains (left wing, right wing), each in tap order.  The two wings advance in
@@ -510,11 +526,32 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
 #endif
             int k = i;
             for (; i + 4 <= i_max; i += 4) left4(i);
+            for (; k + 4 <= k_max; k += 4) right4(k);
+            // the last one to three taps of a wing: one more block of four with the weights past the end set to zero (fma(0, y, acc) = acc:
+            // the same sum) when its four samples are inside the signal, tap by tap at the signal's edges -- a tap-by-tap tail is a
+            // dependent load round trip per tap
+#ifndef WW_ABL_RS_SCALAR_TAIL
+            if (i < i_max && n - i - 3 >= 0) {
+                const float4 t0 = *reinterpret_cast<const float4*>(l0 + i), t1 = *reinterpret_cast<const float4*>(l1 + i);
+                const f4u yy = *reinterpret_cast<const f4u*>(y + n - i - 3);
+                accl = fmaf(fmaf(eta_l, t1.x - t0.x, t0.x), yy.w, accl);
+                accl = fmaf(i + 1 < i_max ? fmaf(eta_l, t1.y - t0.y, t0.y) : 0.f, yy.z, accl);
+                accl = fmaf(i + 2 < i_max ? fmaf(eta_l, t1.z - t0.z, t0.z) : 0.f, yy.y, accl);
+                i = i_max;
+            }
+            if (k < k_max && n + 4 + k < n_orig) {
+                const float4 t0 = *reinterpret_cast<const float4*>(r0 + k), t1 = *reinterpret_cast<const float4*>(r1 + k);
+                const f4u yy = *reinterpret_cast<const f4u*>(y + n + 1 + k);
+                accr = fmaf(fmaf(eta_r, t1.x - t0.x, t0.x), yy.x, accr);
+                accr = fmaf(k + 1 < k_max ? fmaf(eta_r, t1.y - t0.y, t0.y) : 0.f, yy.y, accr);
+                accr = fmaf(k + 2 < k_max ? fmaf(eta_r, t1.z - t0.z, t0.z) : 0.f, yy.z, accr);
+                k = k_max;
+            }
+#endif
             for (; i < i_max; ++i) {
                 const float w0 = l0[i], w1 = l1[i];
                 accl = fmaf(fmaf(eta_l, w1 - w0, w0), y[n - i], accl);
             }
-            for (; k + 4 <= k_max; k += 4) right4(k);
             for (; k < k_max; ++k) {
                 const float w0 = r0[k], w1 = r1[k];
                 accr = fmaf(fmaf(eta_r, w1 - w0, w0), y[n + k + 1], accr);
