@@ -109,6 +109,92 @@ __device__ __forceinline__ float sample_mono(const uint8_t* __restrict__ p, int6
     return channels > 1 ? s / float(channels) : s;
 }
 
+// Files that need the filter and whose filter fits go to resample_lds_kernel; decode_resample_kernel takes the rest (16 kHz files: no
+// filter at all; rates whose reduced up / down leave a filter too long for LDS: the taps from global memory).  Both kernels are
+// launched over all clips and each skips the other's: the split needs nothing from the host (the descriptors live in device memory).
+constexpr int kRsTaps = 8960;                       // filter taps kept in LDS (44.1 kHz family: 2 * 10 * 441 + 1 = 8821)
+constexpr int kRsSpan = 7168;                       // input frames of one output block, converted to mono float32 once
+constexpr int kRsThreads = 512;
+constexpr int kRsLds = (kRsTaps + kRsSpan) * int(sizeof(float));            // 64,512 B: two workgroups per CU
+
+__device__ __forceinline__ bool resample_in_lds(int up, int down, int half_len) {
+    const int lh = 2 * half_len + 1;
+    return !(up == 1 && down == 1) && lh <= kRsTaps && lh / up + 8 < kRsSpan / 2;
+}
+
+// One workgroup per file.  Output blocks of up to 2048 samples: the block's input span is decoded (sample format, channel mean) into LDS
+// once -- the direct form decodes every input frame once per tap that touches it, ~20 times at 48 kHz --, the filter sits in LDS beside it,
+// and each output is the same fused multiply-add chain in the same order as decode_resample_kernel's (bit-identical results).
+__global__ __launch_bounds__(kRsThreads) void resample_lds_kernel(const uint8_t* __restrict__ raw, const ww_clip_desc* __restrict__ descs,
+                                                                  int n_clips, int normalize, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];
+    float* tapsL = rs_lds;
+    float* xs = rs_lds + kRsTaps;
+    __shared__ float red[kRsThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const void* taps_loaded = nullptr;
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+        const ww_clip_desc d = descs[clip];
+        const int up = d.up, down = d.down, half_len = d.half_len;
+        if (!resample_in_lds(up, down, half_len)) continue;
+        const uint8_t* __restrict__ p = raw + d.byte_offset;
+        const int64_t n_in = d.n_frames;
+        const int lh = 2 * half_len + 1;
+        if (d.taps_dev != taps_loaded) {                          // consecutive files usually share their rate
+            __syncthreads();
+            const float* __restrict__ taps = reinterpret_cast<const float*>(d.taps_dev);
+            for (int i = tid; i < lh; i += kRsThreads) tapsL[i] = taps[i];
+            taps_loaded = d.taps_dev;
+        }
+        int64_t n_out = n_in * up;
+        n_out = n_out / down + (n_out % down ? 1 : 0);
+        const int n_pre_pad = down - half_len % down;
+        const int n_pre_remove = (half_len + n_pre_pad) / down;
+        float* __restrict__ o = out + int64_t(clip) * kClip;
+        float peak = 0.f;
+        const int64_t total = n_out > d.crop_start + kClip ? n_out : d.crop_start + kClip;   // also writes the zero pad
+        int64_t blk64 = int64_t(kRsSpan - lh / up - 8) * up / down;
+        const int blk = int(blk64 > 2048 ? 2048 : (blk64 < 1 ? 1 : blk64));
+        auto first_in = [&](int64_t c) -> int64_t { return c - lh + 1 <= 0 ? 0 : (c - lh + 1 + up - 1) / up; };
+        auto last_in = [&](int64_t c) -> int64_t {
+            int64_t i = c < 0 ? -1 : c / up;
+            return i > n_in - 1 ? n_in - 1 : i;
+        };
+        for (int64_t j0 = 0; j0 < total; j0 += blk) {
+            const int64_t j1 = (j0 + blk < n_out ? j0 + blk : n_out) - 1;       // last filtered output of the block (j1 < j0: none)
+            const int64_t i_min = first_in((j0 + n_pre_remove) * int64_t(down) - n_pre_pad);
+            const int64_t i_max = j1 >= j0 ? last_in((j1 + n_pre_remove) * int64_t(down) - n_pre_pad) : i_min - 1;
+            __syncthreads();                                      // the previous block's outputs are done with xs (and the taps are in place)
+            for (int64_t i = i_min + tid; i <= i_max; i += kRsThreads) xs[i - i_min] = sample_mono(p, i, d.channels, d.format);
+            __syncthreads();
+            for (int64_t j = j0 + tid; j < j0 + blk && j < total; j += kRsThreads) {
+                float y = 0.f;
+                if (j < n_out) {
+                    const int64_t c = (j + n_pre_remove) * int64_t(down) - n_pre_pad;     // tap index t = c - i*up
+                    const int i_lo = int(first_in(c) - i_min), i_hi = int(last_in(c) - i_min);
+                    int t = int(c - (i_min + i_lo) * up);
+                    for (int i = i_lo; i <= i_hi; ++i, t -= up) y = fmaf(xs[i], tapsL[t], y);
+                    peak = fmaxf(peak, fabsf(y));
+                }
+                const int64_t w = j - d.crop_start;
+                if (w >= 0 && w < kClip) o[w] = y;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) peak = fmaxf(peak, __shfl_xor(peak, off));
+        __syncthreads();
+        if (lane == 0) red[wave] = peak;
+        __syncthreads();
+        peak = red[0];
+#pragma unroll
+        for (int w = 1; w < kRsThreads / 64; ++w) peak = fmaxf(peak, red[w]);
+        if (normalize) {
+            const int64_t valid = n_out - d.crop_start < kClip ? n_out - d.crop_start : kClip;
+            for (int w = tid; w < valid; w += kRsThreads) o[w] = o[w] / peak;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void decode_resample_kernel(const uint8_t* __restrict__ raw,
                                                              const ww_clip_desc* __restrict__ descs, int n_clips,
                                                              int normalize, float* __restrict__ out) {
@@ -116,6 +202,9 @@ __global__ __launch_bounds__(256) void decode_resample_kernel(const uint8_t* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
         const ww_clip_desc d = descs[clip];
+#ifndef WW_ABL_K0_DIRECT
+        if (resample_in_lds(d.up, d.down, d.half_len)) continue;      // resample_lds_kernel's
+#endif
         const uint8_t* __restrict__ p = raw + d.byte_offset;
         const float* __restrict__ taps = reinterpret_cast<const float*>(d.taps_dev);
         const int64_t n_in = d.n_frames;
@@ -200,6 +289,11 @@ int ww_decode_resample(const uint8_t* raw_dev, const ww_clip_desc* descs_dev, in
     const int grid = int(n_clips < resident ? n_clips : resident);
     hipLaunchKernelGGL(decode_resample_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), raw_dev,
                        descs_dev, int(n_clips), normalize, pcm_out_dev);
+#ifndef WW_ABL_K0_DIRECT
+    const int64_t resident2 = int64_t(device_cu_count()) * 2;
+    hipLaunchKernelGGL(resample_lds_kernel, dim3(int(n_clips < resident2 ? n_clips : resident2)), dim3(kRsThreads), kRsLds,
+                       static_cast<hipStream_t>(stream), raw_dev, descs_dev, int(n_clips), normalize, pcm_out_dev);
+#endif
     WW_HIP(hipGetLastError());
     return WW_OK;
 }
