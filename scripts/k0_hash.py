@@ -23,7 +23,7 @@ proc = pkg.AudioProcessor()
 with tempfile.TemporaryDirectory() as tmp:
     paths = []
     for k, (sr, ch, secs) in enumerate(((48000, 1, 1.0), (44100, 2, 1.3), (22050, 1, 0.7), (8000, 1, 1.0), (32000, 2, 2.5), (96000, 1, 1.0),
-                                       (24000, 1, 0.2), (16000, 1, 1.0), (11025, 1, 1.0))):
+                                       (24000, 1, 0.2), (16000, 1, 1.0), (11025, 1, 1.0), (16000, 1, 5923 / 16000), (16000, 1, 3 / 16000), (16000, 2, 1.0))):
         n = int(sr * secs)
         x = (rng.standard_normal((n, ch)) * 6000).astype("<i2")
         for rep in range(3):

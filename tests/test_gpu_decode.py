@@ -48,6 +48,8 @@ CASES = [  # (name, sr, seconds, channels, bits, fmt)
     ("f32_16k_stereo", 16000, 1.0, 2, 32, 3), ("u8_16k", 16000, 0.7, 1, 8, 1), ("s24_16k", 16000, 1.0, 1, 24, 1),
     ("s32_16k", 16000, 0.9, 1, 32, 1), ("s16_44k", 44100, 1.3, 1, 16, 1), ("s16_48k_stereo", 48000, 0.8, 2, 16, 1),
     ("s16_8k", 8000, 1.0, 1, 16, 1), ("s16_22k_long", 22050, 1.9, 1, 16, 1), ("f64_16k", 16000, 0.6, 1, 64, 3), ("f64_32k_stereo", 32000, 1.1, 2, 64, 3),
+    # 11.025 kHz: up / down = 640 / 441, a 12,801-tap filter that does not fit LDS (decode_resample_kernel's direct form); 96 kHz: down = 6
+    ("s16_11k", 11025, 1.2, 1, 16, 1), ("s16_96k", 96000, 0.5, 1, 16, 1), ("s24_24k_stereo", 24000, 1.6, 2, 24, 1),
 ]
 
 
