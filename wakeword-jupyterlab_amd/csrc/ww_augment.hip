@@ -6,12 +6,13 @@
 // pitch_shift = resample(time_stretch(y, 2^(-n/12)), ratio) cut or zero-padded to the input length.
 //
 //   roll_kernel       out[i] = in[(i - shift) mod L]                        (also the copy into the work buffer)
-//   stft_kernel       one workgroup per clip, one frame per wave at a time: window, 1024-point complex FFT of the
-//                     packed real frame (ww_fft.h), real-input split -> D[frame][0..1024] complex64
-//   pv_kernel         phase vocoder: thread = bin, sequential over the output steps; librosa's arithmetic types are
-//                     kept (float32 magnitudes and phase accumulator, float64 phase advance) so that the accumulator
-//                     rounds the same way; angle / magnitude / phasor by short in-kernel forms (round 3) instead of libm's
-//                     atan2f / hypotf / sincosf
+//   stft_pv_kernel    one workgroup per clip: four frames per round (one per wave: window, 1024-point complex FFT of the packed
+//                     real frame (ww_fft.h), real-input split in place) into a ring of eight LDS slabs, then the phase vocoder
+//                     over the output steps whose two columns are there: thread = bin; librosa's arithmetic types are kept
+//                     (float32 magnitudes and phase accumulator, float64 phase advance) so that the accumulator rounds the
+//                     same way; angle / magnitude / phasor by short in-kernel forms instead of libm's atan2f / hypotf / sincosf.
+//                     (stft_kernel + pv_kernel, the two-launch form with the columns in HBM, are kept for the
+//                     WW_AUG_SPLIT_STFT_PV timing build: same bits.)
 //   istft_kernel      Hermitian spectrum -> conj(Z) -> the same forward FFT -> frame, four frames per round into a ring
 //                     of eight LDS slabs; the hop segments a round completes are summed straight from the slabs in
 //                     frame order with the window and its sum-square, centre-trimmed, cropped / zero-padded
