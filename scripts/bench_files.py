@@ -33,7 +33,7 @@ def measure_decode(batch=4096, steps=10, device=0):
     from wakeword_jupyterlab_amd import _native as nat
     dev = torch.device("cuda", device)
     out = {}
-    for sr in (16000, 48000):
+    for sr in (16000, 44100, 48000):
         frames = sr
         base = (pkg.synth.make_clip(3)[: min(16000, frames)] * 20000).astype("<i2")
         one = np.resize(base, frames).astype("<i2").tobytes()
