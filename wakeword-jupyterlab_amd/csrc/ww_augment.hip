@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void roll_kernel(const float* __restrict__ in,
     out[int64_t(clip) * kClip + i] = in[int64_t(clip) * stride + src];
 }
 
+#ifdef WW_AUG_SPLIT_STFT_PV     // timing-only build: the two-launch form (stft_kernel, pv_kernel below) with the columns in HBM
 // ------------------------------------------------------------------------------------------------
 // which = 0: pitch stage, 1: stretch stage (selects the on/off flag)
 __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, const AugDev* __restrict__ plan, int which,
@@ -103,10 +104,14 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
     }
 }
 
+#endif
+
+#ifdef WW_AUG_SPLIT_STFT_PV
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float2 pv_col(const float2* __restrict__ Dc, int f, int k) {
     return f < kAugFrames ? Dc[int64_t(f) * kSpec + k] : make_float2(0.f, 0.f);     // librosa pads two zero columns
 }
+#endif
 
 // atan2 for the vocoder: a = min/max in [0, 1], atan(a) = a P(a^2) (degree 8 in a^2, |err| <= 1.2e-7 in float32 evaluation -- the size of
 // libm's own last-place error at these magnitudes), octant and quadrant folded back; signed zeros and (0, 0) as atan2f has them.
@@ -176,6 +181,7 @@ __device__ __forceinline__ void pv_sincos(float acc, float& sn, float& cs) {
     cs = __builtin_amdgcn_cosf(fr);
 }
 
+#ifdef WW_AUG_SPLIT_STFT_PV
 __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, const AugDev* __restrict__ plan, int which,
                                                  float2* __restrict__ S) {
 #pragma clang fp contract(off)
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(256) void pv_kernel(const float2* __restrict__ D, c
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // stft_kernel + pv_kernel in one pass over the clip: the STFT columns never leave the CU.  Four frames per round (one per wave) are
@@ -441,13 +448,6 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
     int R = (cnt + 3) & ~3;
     if (((R >> 2) & 1) == 0) R += 4;                              // an odd number of 16-byte slots per row spreads the rows over the banks
     // index kKbLen is the pad np.diff(win) gets (the last value again): tab[kKbLen] = tab[kKbLen - 1]
-#ifdef WW_ABL_RS_OLDBUILD
-    for (int i = 0; i < R; ++i)
-        for (int ph = tid; ph < index_step + 2; ph += 1024) {
-            const int j = ph + i * index_step;
-            P[ph * R + i] = (i < cnt && j <= kKbLen) ? tb->kaiser_best[j < kKbLen ? j : kKbLen - 1] : 0.f;
-        }
-#else
     {   // every thread takes (step + 2) * R / 1024 entries, phase-fastest (coalesced table reads), four loads in flight
         const int rows = index_step + 2, total = rows * R;
 #pragma unroll 4
@@ -457,15 +457,10 @@ __global__ __launch_bounds__(1024) void resample_kernel(const float* __restrict_
             P[ph * R + i] = (i < cnt && j <= kKbLen) ? tb->kaiser_best[j < kKbLen ? j : kKbLen - 1] : 0.f;
         }
     }
-#endif
     __syncthreads();
     const int n_orig = plan[clip].p_len, n_res = plan[clip].p_res;
     const float* y = Y + int64_t(clip) * kAugYStride;
     const double inv = 1.0 / ratio;
-#ifdef WW_ABL_RS_NOMAIN               // timing-only ablation: the table build alone
-    for (int t = tid; t < kClip; t += 1024) o[t] = P[t];
-    return;
-#endif
     for (int t = tid; t < kClip; t += 1024) {
         // positions and table fractions in float64 (t / ratio needs ~15 integer + 9 fraction bits); the ~140 products per
         // output are float32 FMAs in two independent chains (left wing, right wing), each in tap order.  The two wings advance in
