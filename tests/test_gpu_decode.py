@@ -12,7 +12,8 @@ import torch
 
 import wakeword_jupyterlab_amd as pkg
 from oracle import decode_oracle, mel_oracle
-from wakeword_jupyterlab_amd.audio import AudioProcessor, _read_wav
+from wakeword_jupyterlab_amd.audio import AudioProcessor
+from wavio import _read_wav
 
 pytestmark = pytest.mark.gpu
 
@@ -148,3 +149,44 @@ def test_reader_slots_overlap_without_corrupting_batches(tmp_path):
     assert ok.all() and np.abs(out[0].cpu().numpy() - decode_oracle.load_normalise_crop(*_read_wav(long), start)).max() <= 2e-7
     assert np.abs(out[1].cpu().numpy() - refs[0]).max() <= 2e-7
     rd.close()
+
+
+def test_per_file_api_is_the_reader_and_k0(tmp_path, capsys):
+    """load_audio (:65-71) and process_audio_file (:125-138), one file at a time: native reader -> K0 (-> K1), no host decode.
+    load_audio returns the WHOLE file at 16 kHz (one K0 window per second of output)."""
+    x = pkg.synth.make_clip(3) * 0.5
+    p16 = os.path.join(tmp_path, "a.wav"); _write_wav(p16, x)
+    pf = os.path.join(tmp_path, "f.wav"); _write_wav(pf, x, fmt=3)
+    p8 = os.path.join(tmp_path, "u8.wav"); _write_wav(p8, x, bits=8)
+    pst = os.path.join(tmp_path, "st.wav"); _write_wav(pst, np.stack([x, -x * 0.5], 1), channels=2)
+    long = os.path.join(tmp_path, "long44.wav"); _write_wav(long, _tone(int(44100 * 2.3), 44100, 5) * 0.7, sr=44100)
+    short = os.path.join(tmp_path, "short.wav"); _write_wav(short, x[:5000])
+    proc = AudioProcessor()
+    a = proc.load_audio(p16)
+    assert a.dtype == np.float32 and a.shape == (16000,) and np.abs(a - x).max() < 1 / 32768 + 1e-7
+    assert np.array_equal(proc.load_audio(pf), x.astype(np.float32))
+    assert np.abs(proc.load_audio(p8) - x).max() < 1 / 64
+    assert np.abs(proc.load_audio(pst) - 0.25 * x).max() < 1e-4              # mono = channel mean, as librosa.load
+    assert proc.load_audio(short).shape == (5000,)
+    samples, sr = _read_wav(long)
+    want = decode_oracle.decode(samples, sr)
+    got = proc.load_audio(long)
+    assert got.shape == want.shape and len(got) > 2 * 16000 and np.abs(got - want).max() <= 5e-6      # three K0 windows, stitched
+    # failure: print + None, never raise (reference :66-71)
+    bad = os.path.join(tmp_path, "bad.wav"); open(bad, "wb").write(b"not a wav")
+    assert proc.load_audio(bad) is None and proc.load_audio(os.path.join(tmp_path, "missing.wav")) is None
+    assert proc.process_audio_file(bad) is None
+    assert "Error loading" in capsys.readouterr().out
+    # process_audio_file = the batched path with one file, bit for bit; the crop is python random's draw, as pad_or_truncate's
+    m = proc.process_audio_file(p16)
+    pcm, ok = proc.load_clips_gpu([p16])
+    assert m.shape == (80, 32) and np.array_equal(m, proc.mel_batch(pcm, normalize=False)[0, 0].cpu().numpy())
+    random.seed(5)
+    m_long = proc.process_audio_file(long)
+    random.seed(5)
+    start = random.randint(0, len(want) - 16000)
+    ref = proc.audio_to_mel(decode_oracle.load_normalise_crop(samples, sr, start))
+    assert np.abs(m_long - ref).max() <= 1e-3                                  # dB; the clips differ by the resampler's float32 sums
+    random.seed(11)
+    m_aug = proc.process_audio_file(p16, augment=True)
+    assert m_aug.shape == (80, 32) and np.isfinite(m_aug).all() and not np.array_equal(m_aug, m)

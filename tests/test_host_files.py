@@ -3,7 +3,7 @@ staging buffer, status codes, capacity handling.  The same code path feeds pinne
 (tests/test_gpu_decode.py drives it through K0 against oracle/decode_oracle.py).
 
 Reference behaviour being replaced: AudioProcessor.load_audio, /root/reference/wakeword_training_script.py:65-71 (one file at a
-time, print + None on failure); the expected header fields come from audio._parse_wav, the package's own host parser.
+time, print + None on failure); the expected header fields come from tests/wavio.py, the tests' own numpy parser.
 """
 import ctypes as C
 import os
@@ -15,7 +15,7 @@ import pytest
 import wakeword_jupyterlab_amd as pkg
 from wakeword_jupyterlab_amd import _native as nat
 from wakeword_jupyterlab_amd import files
-from wakeword_jupyterlab_amd.audio import _parse_wav
+from wavio import _parse_wav
 
 
 def _chunk(cid, body):

@@ -17,7 +17,7 @@ def __getattr__(name):
     import importlib
     if name in ("ops", "model", "audio", "dataset", "streaming", "inference", "distributed", "_native"):
         return importlib.import_module(f"{__name__}.{name}")
-    lazy = {"AudioProcessor": "audio", "WakewordDataset": "dataset", "SimpleWakewordModel": "model",
+    lazy = {"AudioProcessor": "audio", "WakewordDataset": "dataset", "DataLoader": "dataset", "SimpleWakewordModel": "model",
             "WakewordModel": "model", "StreamingDetector": "streaming", "predict_wakeword": "inference",
             "evaluate": "inference", "AudioConfig": "config", "ModelConfig": "config", "Config": "config",
             "AugmentationConfig": "config"}

@@ -11,84 +11,19 @@ plus the batched form the GPU wants: `mel_batch(pcm[B, n]) -> torch.Tensor [B, 1
 
   augment_audio(audio)        -> time shift / pitch shift / time stretch / noise, each with probability 0.8
                                  (random draws from python `random` in the reference's order)  <- HIP kernels KA
-`load_audio` decodes PCM / float WAV with the standard library and resamples with scipy's polyphase
-filter -- NOT librosa's decoder + soxr resampler; moving decode+resample to the GPU is the first
-"next" row.
+`load_audio` / `process_audio_file` read the file with the library's native reader (csrc/ww_files.cpp) and decode, mix down and
+resample it on the GPU (kernel K0: scipy.signal.resample_poly's Kaiser design -- NOT librosa's soxr resampler, an absent third-party
+library: parity unpinned) -- the same code path as the batched loaders, one file at a time.  PCM / float WAV only.
 """
 from __future__ import annotations
 
 import random
-import wave
 
 import numpy as np
 import torch
 
 from . import ops
 from .config import AudioConfig, AugmentationConfig, check_audio_config
-
-
-def _parse_wav(data: bytes):
-    """RIFF/WAVE header walk -> (format tag, channels, sample rate, bits, data offset, data length)."""
-    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
-        raise ValueError("not a RIFF/WAVE file")
-    pos, fmt, where = 12, None, None
-    while pos + 8 <= len(data):
-        cid, size = data[pos:pos + 4], int.from_bytes(data[pos + 4:pos + 8], "little")
-        if cid == b"fmt ":
-            body = data[pos + 8:pos + 8 + size]
-            tag, ch, sr = int.from_bytes(body[0:2], "little"), int.from_bytes(body[2:4], "little"), int.from_bytes(body[4:8], "little")
-            bits = int.from_bytes(body[14:16], "little")
-            if tag == 0xFFFE and len(body) >= 26:
-                tag = int.from_bytes(body[24:26], "little")
-            fmt = (tag, ch, sr, bits)
-        elif cid == b"data":
-            where = (pos + 8, min(size, len(data) - pos - 8))
-        pos += 8 + size + (size & 1)
-    if fmt is None or where is None:
-        raise ValueError("missing fmt/data chunk")
-    return fmt + where
-
-
-def _read_wav(path: str):
-    """Minimal RIFF/WAVE reader: 8/16/24/32-bit PCM and 32-bit float, any channel count -> (float32 [n, ch], sr)."""
-    with open(path, "rb") as f:
-        data = f.read()
-    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
-        raise ValueError("not a RIFF/WAVE file")
-    pos, fmt, pcm = 12, None, None
-    while pos + 8 <= len(data):
-        cid, size = data[pos:pos + 4], int.from_bytes(data[pos + 4:pos + 8], "little")
-        body = data[pos + 8:pos + 8 + size]
-        if cid == b"fmt ":
-            tag, ch, sr = int.from_bytes(body[0:2], "little"), int.from_bytes(body[2:4], "little"), int.from_bytes(body[4:8], "little")
-            bits = int.from_bytes(body[14:16], "little")
-            if tag == 0xFFFE and len(body) >= 26:          # WAVE_FORMAT_EXTENSIBLE: real tag in the GUID
-                tag = int.from_bytes(body[24:26], "little")
-            fmt = (tag, ch, sr, bits)
-        elif cid == b"data":
-            pcm = body
-        pos += 8 + size + (size & 1)
-    if fmt is None or pcm is None:
-        raise ValueError("missing fmt/data chunk")
-    tag, ch, sr, bits = fmt
-    if tag == 1 and bits == 8:
-        x = (np.frombuffer(pcm, np.uint8).astype(np.float32) - 128.0) / 128.0
-    elif tag == 1 and bits == 16:
-        x = np.frombuffer(pcm[: len(pcm) // 2 * 2], "<i2").astype(np.float32) / 32768.0
-    elif tag == 1 and bits == 24:
-        b = np.frombuffer(pcm[: len(pcm) // 3 * 3], np.uint8).reshape(-1, 3).astype(np.int32)
-        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-        x = (np.where(v >= 1 << 23, v - (1 << 24), v)).astype(np.float32) / float(1 << 23)
-    elif tag == 1 and bits == 32:
-        x = np.frombuffer(pcm[: len(pcm) // 4 * 4], "<i4").astype(np.float32) / float(1 << 31)
-    elif tag == 3 and bits == 32:
-        x = np.frombuffer(pcm[: len(pcm) // 4 * 4], "<f4").astype(np.float32)
-    elif tag == 3 and bits == 64:
-        x = np.frombuffer(pcm[: len(pcm) // 8 * 8], "<f8").astype(np.float32)
-    else:
-        raise ValueError(f"unsupported WAV encoding tag={tag} bits={bits}")
-    x = x[: len(x) // ch * ch].reshape(-1, ch)
-    return x, sr
 
 
 class AudioProcessor:
@@ -106,14 +41,29 @@ class AudioProcessor:
 
     # ---- reference API --------------------------------------------------------------------------
     def load_audio(self, file_path):
+        """= librosa.load(path, sr=16000) (:65-71): the WHOLE file as float32 at 16 kHz mono, or None (prints the error, never raises on a
+        bad file).  Native reader -> K0, one second of output per launch (K0 writes 1 s windows); no normalisation, no crop."""
+        from . import _native as nat
+        from .files import CLIP_SAMPLES
+        rd = self.gpu_reader(1)                                   # raises without a GPU: a missing device is not a bad file
         try:
-            x, sr = _read_wav(file_path)
-            audio = x.mean(axis=1) if x.shape[1] > 1 else x[:, 0]           # librosa.load mono=True
-            if sr != self.config.SAMPLE_RATE:
-                from math import gcd
-                from scipy.signal import resample_poly
-                g = gcd(int(sr), int(self.config.SAMPLE_RATE))
-                audio = resample_poly(audio.astype(np.float64), self.config.SAMPLE_RATE // g, sr // g)
+            slot = rd.next_slot()
+            try:
+                descs, status = rd.read([file_path], slot)
+            except nat.NativeError as e:
+                if e.code != nat.WW_ENOSPACE:
+                    raise
+                rd.regrow(1, int(e.needed * 1.25) + 4096)
+                slot = rd.next_slot()
+                descs, status = rd.read([file_path], slot)
+            if status[0] != 1:
+                raise ValueError(nat.WAV_STATUS.get(int(status[0]), int(status[0])))
+            n_out = int(-(-(int(descs["n_frames"][0]) * int(descs["up"][0])) // max(1, int(descs["down"][0]))))
+            parts = []
+            for start in range(0, n_out, CLIP_SAMPLES):
+                descs["crop_start"][0] = start
+                parts.append(rd.decode(slot, normalize=False)[0].cpu())          # .cpu() synchronises: the descriptor may change again
+            audio = torch.cat(parts)[:n_out].numpy() if parts else np.zeros(0, dtype=np.float32)
             return np.ascontiguousarray(audio, dtype=np.float32)
         except Exception as e:                                             # reference: print and return None (:66-71)
             print(f"Error loading {file_path}: {e}")
@@ -176,14 +126,14 @@ class AudioProcessor:
         return self.augment_batch(a[None, :], config=config)[0].cpu().numpy()
 
     def process_audio_file(self, file_path, augment=False):
-        audio = self.load_audio(file_path)
-        if audio is None:
+        """load -> normalise over the whole file -> random crop / zero pad -> (augment) -> log-mel (:125-138), all on the GPU:
+        native reader -> K0 -> (KA) -> K1.  The random draws are python `random`'s in the reference's order (crop, then augmentation)."""
+        pcm, ok = self.load_clips_gpu([file_path])
+        if not bool(ok[0]):
             return None
-        audio = self.normalize_audio(audio)
-        audio = self.pad_or_truncate(audio, int(self.config.SAMPLE_RATE * self.config.DURATION))
         if augment:
-            audio = self.augment_audio(audio)
-        return self.audio_to_mel(audio)
+            pcm = self.augment_batch(pcm)
+        return self.mel_batch(pcm, normalize=False)[0, 0].cpu().numpy()
 
     # ---- batched form ---------------------------------------------------------------------------
     def mel_batch(self, pcm, normalize: bool = True) -> torch.Tensor:
@@ -215,17 +165,3 @@ class AudioProcessor:
         elif self._reader.max_clips < batch_size:
             self._reader.regrow(batch_size, batch_size * 65536)
         return self._reader
-
-    def load_clips(self, paths, target_length=None):
-        """Decode, peak-normalise and crop/pad a list of files on the host, in the reference's order
-        (process_audio_file :125-138) -> (float32 [B, 16000], ok mask).  Feed to mel_batch(normalize=False)."""
-        n = target_length or int(self.config.SAMPLE_RATE * self.config.DURATION)
-        out = np.zeros((len(paths), n), dtype=np.float32)
-        ok = np.zeros(len(paths), dtype=bool)
-        for i, p in enumerate(paths):
-            a = self.load_audio(p)
-            if a is None:
-                continue
-            out[i] = self.pad_or_truncate(self.normalize_audio(a), n)
-            ok[i] = True
-        return out, ok

@@ -52,10 +52,10 @@ class WakewordDataset(Dataset):
             mel_spec = np.zeros((self.processor.config.N_MELS, N_FRAMES))
         return torch.FloatTensor(np.asarray(mel_spec, dtype=np.float32)).unsqueeze(0), torch.LongTensor([self.labels[idx]])
 
-    def batches(self, batch_size=16, gpu_decode=True):
-        """Yield (data [B,1,80,32] on the GPU, target [B,1] on the GPU) in file order.
-        gpu_decode=True: the host only reads bytes; decode/resample/normalise/crop run in kernel K0, log-mel in K1."""
-        return iter(GpuBatchLoader(self, batch_size, shuffle=False, gpu_decode=gpu_decode))
+    def batches(self, batch_size=16):
+        """Yield (data [B,1,80,32] on the GPU, target [B,1] on the GPU) in file order: the host only reads bytes;
+        decode / resample / normalise / crop run in kernel K0, log-mel in K1."""
+        return iter(GpuBatchLoader(self, batch_size, shuffle=False))
 
     def loader(self, batch_size=16, shuffle=False, drop_last=False):
         """What `DataLoader(dataset, batch_size=.., shuffle=.., num_workers=2)` is to the reference's loops
@@ -67,10 +67,10 @@ class WakewordDataset(Dataset):
 
 
 class GpuBatchLoader:
-    def __init__(self, dataset, batch_size=16, shuffle=False, drop_last=False, gpu_decode=True):
+    def __init__(self, dataset, batch_size=16, shuffle=False, drop_last=False):
         if batch_size < 1:
             raise ValueError("batch_size must be positive")
-        self.dataset, self.batch_size, self.shuffle, self.drop_last, self.gpu_decode = dataset, int(batch_size), bool(shuffle), bool(drop_last), gpu_decode
+        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), bool(shuffle), bool(drop_last)
         self._encoded = None
 
     def __len__(self):
@@ -89,22 +89,16 @@ class GpuBatchLoader:
         idx = self.order()
         files = [ds.files[i] for i in idx]
         labels = [ds.labels[i] for i in idx]
-        enc = None
-        if self.gpu_decode:
-            from .files import EncodedPaths
-            if not self.shuffle:
-                if self._encoded is None:
-                    self._encoded = EncodedPaths(files)       # the file list as the native reader takes it, converted once
-                enc = self._encoded
-            else:
-                enc = EncodedPaths(files)                     # this epoch's order
+        from .files import EncodedPaths
+        if not self.shuffle:
+            if self._encoded is None:
+                self._encoded = EncodedPaths(files)           # the file list as the native reader takes it, converted once
+            enc = self._encoded
+        else:
+            enc = EncodedPaths(files)                         # this epoch's order
+
         def decoded():
-            """(first index, pcm on the device, ok mask) per batch: the native reader one batch ahead (files.WavBatchReader.stream), or the host path."""
-            if not self.gpu_decode:
-                for s in range(0, len(files), self.batch_size):
-                    pcm, ok = ds.processor.load_clips(files[s:s + self.batch_size])
-                    yield s, torch.from_numpy(pcm).to(dev), ok
-                return
+            """(first index, pcm on the device, ok mask) per batch: the native reader one batch ahead (files.WavBatchReader.stream)."""
             from . import _native as nat
             reader = ds.processor.gpu_reader(self.batch_size)
             s = 0
@@ -131,3 +125,21 @@ class GpuBatchLoader:
                 data[torch.from_numpy(~ok).to(dev)] = 0.0
             target = torch.tensor(labels[s:e], dtype=torch.long, device=dev).unsqueeze(1)
             yield data, target
+
+
+def DataLoader(dataset, batch_size=1, shuffle=False, *args, num_workers=0, drop_last=False, **kwargs):
+    """Drop-in for the name the reference imports (`from torch.utils.data import Dataset, DataLoader`,
+    /root/reference/wakeword_training_script.py:9): with it the script's loader lines (:461-463,
+    `DataLoader(train_dataset, batch_size=16, shuffle=True, num_workers=2)`) run unchanged.  For a WakewordDataset it returns
+    `dataset.loader(batch_size, shuffle, drop_last)` -- `num_workers` is accepted and not used: the library's reader threads and the GPU
+    kernels do what the worker processes did (a forked worker could not touch the GPU anyway).  Any other dataset goes to torch's
+    DataLoader untouched.  A sampler / batch_sampler / collate_fn on a WakewordDataset is refused (the batch is built on the GPU)."""
+    if isinstance(dataset, WakewordDataset):
+        unsupported = [k for k in ("sampler", "batch_sampler", "collate_fn") if kwargs.get(k) is not None]
+        if args or unsupported:
+            raise NotImplementedError("DataLoader(WakewordDataset, ...): positional extras / " + ", ".join(unsupported or ["sampler"]) +
+                                      " are not supported -- the batch is assembled on the GPU (dataset.loader)")
+        if batch_size is None:
+            raise NotImplementedError("DataLoader(WakewordDataset, batch_size=None): unbatched loading is dataset[i]")
+        return dataset.loader(batch_size=batch_size, shuffle=bool(shuffle), drop_last=bool(drop_last))
+    return torch.utils.data.DataLoader(dataset, batch_size, shuffle, *args, num_workers=num_workers, drop_last=drop_last, **kwargs)
