@@ -169,12 +169,23 @@ __global__ __launch_bounds__(kRsThreads) void resample_lds_kernel(const uint8_t*
             __syncthreads();                                      // the previous block's outputs are done with xs (and the taps are in place)
             for (int64_t i = i_min + tid; i <= i_max; i += kRsThreads) xs[i - i_min] = sample_mono(p, i, d.channels, d.format);
             __syncthreads();
-            for (int64_t j = j0 + tid; j < j0 + blk && j < total; j += kRsThreads) {
+            // inside a block everything is 32-bit and relative to the block's first input frame: c - i_min * up fits easily (span * up),
+            // and since i_min * up is a multiple of up the floor / ceiling divisions carry over (64-bit divides per output cost as much as its taps)
+            const int crel0 = int((j0 + n_pre_remove) * int64_t(down) - n_pre_pad - i_min * up);
+            const int64_t room = n_in - 1 - i_min;
+            const int i_cap = room < kRsSpan ? int(room) : kRsSpan;
+            const int jn = int((j0 + blk < total ? j0 + blk : total) - j0);
+            for (int jj = tid; jj < jn; jj += kRsThreads) {
+                const int64_t j = j0 + jj;
                 float y = 0.f;
                 if (j < n_out) {
-                    const int64_t c = (j + n_pre_remove) * int64_t(down) - n_pre_pad;     // tap index t = c - i*up
-                    const int i_lo = int(first_in(c) - i_min), i_hi = int(last_in(c) - i_min);
-                    int t = int(c - (i_min + i_lo) * up);
+                    const int crel = crel0 + jj * down;                       // = c - i_min * up, c the output's centre tap position
+                    const int x = crel - lh + 1;
+                    const int i_lo = x <= 0 ? 0 : (x + up - 1) / up;
+                    int i_hi = crel < 0 ? -1 : crel / up;
+                    i_hi = i_hi < i_cap ? i_hi : i_cap;
+                    int t = crel - i_lo * up;
+#pragma unroll 8
                     for (int i = i_lo; i <= i_hi; ++i, t -= up) y = fmaf(xs[i], tapsL[t], y);
                     peak = fmaxf(peak, fabsf(y));
                 }
