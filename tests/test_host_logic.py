@@ -173,3 +173,23 @@ def test_dataloader_name_routes_wakeword_datasets_to_the_gpu_loader(tmp_path):
     plain = torch.utils.data.TensorDataset(torch.arange(10.0))
     tl = DataLoader(plain, batch_size=4, shuffle=False, num_workers=0)
     assert isinstance(tl, torch.utils.data.DataLoader) and [len(b[0]) for b in tl] == [4, 4, 2]
+
+
+def test_create_sample_data_writes_the_reference_layout(tmp_path, capsys):
+    """create_sample_data (:350-392): 50 + 100 + 20 files, 16 kHz mono PCM-16, the reference's names; numpy's global generator repeats them."""
+    np.random.seed(3)
+    pkg.synth.create_sample_data(str(tmp_path))
+    assert "Wakeword samples: 50" in capsys.readouterr().out
+    counts = {d: sorted(os.listdir(os.path.join(tmp_path, d))) for d in ("wakeword_data", "negative_data", "background_noise")}
+    assert [len(v) for v in counts.values()] == [50, 100, 20]
+    assert counts["wakeword_data"][0] == "wakeword_000.wav" and counts["negative_data"][-1] == "negative_099.wav" and counts["background_noise"][7] == "noise_007.wav"
+    x, sr = _read_wav(os.path.join(tmp_path, "wakeword_data", "wakeword_000.wav"))
+    assert sr == 16000 and x.shape == (16000, 1)
+    spec = np.abs(np.fft.rfft(x[:, 0].astype(np.float64)))
+    assert spec.argmax() == 200 and spec[400] > 0.5 * spec[200]                    # 200 Hz + its harmonic over the noise
+    n, _ = _read_wav(os.path.join(tmp_path, "background_noise", "noise_000.wav"))
+    assert n.shape == (80000, 1) and 0.08 < n.std() < 0.12
+    first = open(os.path.join(tmp_path, "negative_data", "negative_000.wav"), "rb").read()
+    np.random.seed(3)
+    pkg.synth.create_sample_data(str(tmp_path))
+    assert open(os.path.join(tmp_path, "negative_data", "negative_000.wav"), "rb").read() == first

@@ -112,3 +112,39 @@ def make_state_dict(arch: str = "simple", seed: int = 1234, hidden: int = 256) -
     sd["fc.weight"] = _u(seed, 100 + s, (2, hidden), b); s += 1
     sd["fc.bias"] = _u(seed, 100 + s, (2,), b); s += 1
     return sd
+
+
+def write_wav16(path: str, audio: np.ndarray, sr: int = SAMPLE_RATE) -> None:
+    """What `soundfile.write(path, float_audio, sr)` leaves on disk for a mono float array: RIFF/WAVE, PCM-16 (libsndfile's default subtype
+    for .wav; full scale = 32767, clipped here where libsndfile would wrap)."""
+    import struct
+    raw = np.clip(np.rint(np.asarray(audio, dtype=np.float64) * 32767.0), -32768, 32767).astype("<i2").tobytes()
+    hdr = (b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16) +
+           b"data" + struct.pack("<I", len(raw)))
+    with open(path, "wb") as f:
+        f.write(hdr + raw)
+
+
+def create_sample_data(root: str = ".") -> None:
+    """`create_sample_data()` of the reference (/root/reference/wakeword_training_script.py:350-392): 50 wakeword clips (0.1 randn + 200 Hz +
+    400 Hz), 100 negatives (0.2 randn), 20 five-second noise files, 16 kHz mono PCM-16 WAV, same directory and file names, drawn from
+    numpy's global generator like the reference (np.random.seed repeats them).  Host-only convenience for the script's `main`."""
+    import os
+    print("Creating sample data for training...")
+    for d in ("wakeword_data", "negative_data", "background_noise"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    sr = SAMPLE_RATE
+    for i in range(50):
+        audio = np.random.randn(sr) * 0.1
+        t = np.linspace(0, 1.0, sr)
+        audio += np.sin(2 * np.pi * 200 * t) * 0.3
+        audio += np.sin(2 * np.pi * 400 * t) * 0.2
+        write_wav16(os.path.join(root, "wakeword_data", f"wakeword_{i:03d}.wav"), audio, sr)
+    for i in range(100):
+        write_wav16(os.path.join(root, "negative_data", f"negative_{i:03d}.wav"), np.random.randn(sr) * 0.2, sr)
+    for i in range(20):
+        write_wav16(os.path.join(root, "background_noise", f"noise_{i:03d}.wav"), np.random.randn(5 * sr) * 0.1, sr)
+    print("Sample data created successfully!")
+    print("   Wakeword samples: 50")
+    print("   Negative samples: 100")
+    print("   Background noise samples: 20")
