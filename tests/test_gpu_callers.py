@@ -282,3 +282,71 @@ def test_streaming_256_microphones_10ms_hop():
             checked += 1
     assert checked >= 13
     det.close()
+
+
+def test_the_reference_main_flow_with_only_the_imports_changed(dev, tmp_path, capsys):
+    """`main()` of wakeword_training_script.py:395-495 with the package's names in place of the script's class definitions: create_sample_data
+    -> file lists -> split -> AudioProcessor / WakewordModel().to(device) -> three WakewordDatasets (training split augmented) -> the
+    DataLoader(..., num_workers=2) lines as written -> WakewordTrainer's train_epoch / validate loop bodies (:241-289, restated here: the
+    reference cannot travel) -> checkpoint dict -> load_checkpoint.  The synthetic classes (tone + noise vs noise) are separable: a few
+    epochs must learn them."""
+    import glob
+    import random
+    from wakeword_jupyterlab_amd import DataLoader, WakewordModel
+    from wakeword_jupyterlab_amd.synth import create_sample_data
+    np.random.seed(0); random.seed(0); torch.manual_seed(0)
+    create_sample_data(str(tmp_path))
+    wake = sorted(glob.glob(os.path.join(tmp_path, "wakeword_data", "*.wav")))
+    neg = sorted(glob.glob(os.path.join(tmp_path, "negative_data", "*.wav")))
+    assert (len(wake), len(neg)) == (50, 100)
+    rng = random.Random(42)
+    rng.shuffle(wake); rng.shuffle(neg)
+    w_tr, w_va, w_te = wake[:36], wake[36:45], wake[45:]
+    n_tr, n_va, n_te = neg[:72], neg[72:90], neg[90:]
+    processor = AudioProcessor()
+    model = WakewordModel().to(dev)
+    train_loader = DataLoader(WakewordDataset(w_tr, n_tr, processor, augment=True, verbose=False), batch_size=16, shuffle=True, num_workers=2)
+    val_loader = DataLoader(WakewordDataset(w_va, n_va, processor, augment=False, verbose=False), batch_size=16, shuffle=False, num_workers=2)
+    test_loader = DataLoader(WakewordDataset(w_te, n_te, processor, augment=False, verbose=False), batch_size=16, shuffle=False, num_workers=2)
+    criterion = torch.nn.CrossEntropyLoss().to(dev)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+
+    def run(loader, train):
+        model.train() if train else model.eval()
+        loss_sum, correct, total = 0.0, 0, 0
+        with torch.enable_grad() if train else torch.no_grad():
+            for data, target in loader:
+                data, target = data.to(dev), target.to(dev).squeeze()
+                if train:
+                    optimizer.zero_grad()
+                output = model(data)
+                loss = criterion(output, target)
+                if train:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+                    loss.backward()
+                    optimizer.step()
+                loss_sum += loss.item()
+                _, predicted = torch.max(output.data, 1)
+                total += target.size(0)
+                correct += (predicted == target).sum().item()
+        return loss_sum / len(loader), 100.0 * correct / total
+
+    history = []
+    for epoch in range(4):
+        tl, ta = run(train_loader, True)
+        vl, va = run(val_loader, False)
+        history.append((tl, ta, vl, va))
+    print("history", history)
+    assert all(np.isfinite(h).all() for h in history)
+    assert history[-1][0] < history[0][0] and history[-1][3] >= 90.0, history
+    _, test_acc = run(test_loader, False)
+    assert test_acc >= 90.0, test_acc
+    path = os.path.join(tmp_path, "best_wakeword_model.pth")
+    torch.save({"epoch": 3, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(), "val_acc": history[-1][3]}, path)
+    m2 = WakewordModel().to(dev)
+    ckpt = load_checkpoint(m2, path, map_location=dev)
+    assert ckpt["epoch"] == 3
+    m2.eval(); model.eval()
+    data, _ = next(iter(test_loader))
+    with torch.no_grad():
+        assert torch.equal(m2(data), model(data))
