@@ -16,6 +16,7 @@ import wakeword_jupyterlab_amd as pkg  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--repeat", type=int, default=1, help="run the same augmentation this many times; every run must give the same bits")
 args = ap.parse_args()
 x = pkg.synth.make_clips_tiled(0, args.batch, unique=64)
 x = x / np.abs(x).max(axis=1, keepdims=True)
@@ -25,4 +26,9 @@ proc = pkg.AudioProcessor()
 plans = [proc.draw_augment_plan() for _ in range(args.batch)]
 out = proc.augment_batch(pcm, plans)
 torch.cuda.synchronize()
+bad = 0
+for _ in range(args.repeat - 1):
+    bad += int(not torch.equal(proc.augment_batch(pcm, plans), out))
+if args.repeat > 1:
+    print(f"{args.repeat} runs, {bad} differing from the first")
 print(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest(), os.environ.get("WW_LIB_OVERRIDE", "shipped"))
