@@ -54,11 +54,18 @@ struct AugDev {            // one per clip, derived on the host from ww_augment_
 __global__ __launch_bounds__(256) void roll_kernel(const float* __restrict__ in, int64_t stride, const AugDev* __restrict__ plan,
                                                    float* __restrict__ out) {
     const int clip = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = 4 * (blockIdx.x * 256 + threadIdx.x);          // four outputs per thread: one 16-byte store (kClip % 4 == 0)
     if (i >= kClip) return;
+    const float* __restrict__ x = in + int64_t(clip) * stride;
     int src = i - plan[clip].shift;
     src += src < 0 ? kClip : 0;
-    out[int64_t(clip) * kClip + i] = in[int64_t(clip) * stride + src];
+    float4 v;
+    if (src + 3 < kClip) { v.x = x[src]; v.y = x[src + 1]; v.z = x[src + 2]; v.w = x[src + 3]; }
+    else {                                                       // the wrap falls inside this group of four
+        v.x = x[src]; v.y = x[src + 1 < kClip ? src + 1 : src + 1 - kClip];
+        v.z = x[src + 2 < kClip ? src + 2 : src + 2 - kClip]; v.w = x[src + 3 - kClip];
+    }
+    *reinterpret_cast<float4*>(out + int64_t(clip) * kClip + i) = v;
 }
 
 #ifdef WW_AUG_SPLIT_STFT_PV     // timing-only build: the two-launch form (stft_kernel, pv_kernel below) with the columns in HBM
@@ -690,7 +697,7 @@ int launch_augment_records(const float* pcm, int64_t n, int64_t stride, const vo
             attr[dev] = true;
         }
     }
-    const dim3 egrid((kClip + 255) / 256, unsigned(n));
+    const dim3 egrid((kClip / 4 + 255) / 256, unsigned(n));
     hipLaunchKernelGGL(roll_kernel, egrid, dim3(256), 0, stream, pcm, stride, plan, bufA);
     float* cur = bufA;
     float* other = bufB;
