@@ -307,6 +307,27 @@ __device__ __forceinline__ void conv1_rows_mfma(const _Float16* __restrict__ mh,
 // counted in g_sync_timeouts, which the host reads with ww_sync_timeouts() (the GPU tests assert that it stays 0).
 __device__ unsigned int g_sync_timeouts;
 
+// Diagnostic build -DWW_CLOCK (never in the shipped library): consumer wave 1 of every workgroup stamps s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) around its loop; ww_debug_clock() returns the sums -> in-kernel clock = cycles / ticks * 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to a buffer of their own; no output is computed from them.
+#ifdef WW_CLOCK
+__device__ unsigned long long g_clk[4];
+#define CLK_BEGIN() unsigned long long clk_c0 = 0, clk_r0 = 0; \
+    if (wave == 1) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#define CLK_END() do { if (wave == 1 && lane == 0) { \
+    atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - clk_c0); atomicAdd(&g_clk[1], __builtin_amdgcn_s_memrealtime() - clk_r0); \
+    atomicAdd(&g_clk[2], 1ull); } } while (0)
+extern "C" __attribute__((visibility("default"))) int ww_debug_clock(unsigned long long* out) {
+    unsigned long long z[4] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(z)) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z));
+    return 0;
+}
+#else
+#define CLK_BEGIN() do {} while (0)
+#define CLK_END() do {} while (0)
+#endif
+
 // The fences are executed by EVERY lane (the counter itself only by lane 0 / read by all): release and acquire order the
 // LDS accesses of the work-item that executes them, and a tile is written and read by all 64 lanes of a wave.
 __device__ __forceinline__ void flag_signal(uint32_t* f) {
@@ -908,6 +929,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
         __builtin_amdgcn_s_setprio(WW_WINO_CPRIO);
 #endif
         const int gsteps = my_clips * kWPerGroup;
+        CLK_BEGIN();
         for (int q = 0; q < gsteps; ++q) {
             const int k = q / kWPerGroup, sq = q - k * kWPerGroup;
             const int b = grp * kWRing + q % kWRing;
@@ -1023,6 +1045,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                 }
             }
         }
+        CLK_END();
     }
     // an expired wait anywhere in this workgroup: poison everything it produced (pooled features, or the conv3 scale)
     __syncthreads();
@@ -1032,6 +1055,364 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
             const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
             if constexpr (POOL) { if (tid < 64) out[clip * 64 + tid] = nan; }
             else { if (tid == 0) apow2[clip] = nan; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cnn2x_kernel: the same 1-D Winograd F(2,3) conv1 + conv2 + ReLU + pool as cnn2w_kernel with the consumers on
+// v_mfma_f32_32x32x16_f16 (round 4).  Why: cnn2w_kernel is bound by the SIMDs' vector-issue port, not by the matrix pipe
+// (profiles/r04_k2_census.txt): a 16x16x32 MFMA holds the port for 8 of its 16 cycles, a 32x32x16 one for 8 of its 32 -- half the
+// issue cost per flop -- and an N-tile of 32 channels halves the fragment reads from LDS (each activation fragment now feeds 32
+// output channels).  The price is the register file: a wave with all four xi of a 32-channel N-tile would need 192 B-operand + 64
+// accumulator VGPRs.  So the four xi are SPLIT OVER TWO WAVES:
+//   wave A (xh = 0) accumulates M1, M0      wave B (xh = 1) accumulates M2, M3          (96 B-operand + 32 accumulator VGPRs each)
+//   out[2t]   = M0 + (M1 + M2)  is finished by A, which needs M2 from B
+//   out[2t+1] = (M1 - M2) - M3  is finished by B, which needs M1 from A
+// Each wave runs the xi it gives away FIRST and stores that accumulator (4 KB) into the pair's exchange slot in LDS while the MFMAs of
+// its second xi run; at the end of the tile row it reads the partner's 4 KB and does bias + 2 relu + pool for ITS output row.  The
+// slots are one tile row deep (FULL / FREE counters per direction): partners stay within half a tile row of each other.
+//   waves 0-7   CONSUMERS = (N-tile nt of 32 channels) x (xh) x (group g); wave = nt + 2 xh + 4 g; group g takes the tile rows of
+//               producers 2g and 2g + 1 alternately, as in cnn2w_kernel; 12 fragment steps x 3 MFMAs per tile row and wave
+//   waves 8-11  PRODUCERS, as in cnn2w_kernel
+// Tile row in LDS: [4 planes pi = V1, V0, V2, V3][hi, lo][34 positions][32 ci] f16 = 64-byte records; the four 16-byte chunks of a
+// record are XOR-swizzled with (position >> 2) & 3, which makes the 32x32x16 A-fragment reads (lane = (position, k half): 16 bytes at
+// position * 64 + chunk * 16) conflict-free under the ds_read_b128 lane-group rule (checked by enumeration, scripts/proto/swz.py).
+// ------------------------------------------------------------------------------------------------
+constexpr int kXRec = 64;
+constexpr int kXPlane = kRS * kXRec;                // 2,176: one (plane, half)
+constexpr int kXTile = 8 * kXPlane;                 // 17,408 B per tile row
+constexpr int kXNB = 2 * kWRing;
+constexpr int kXExch = 4 * 2 * 4096;                // [pair = 2 g + nt][direction][16 registers x 64 lanes]
+constexpr int kCXLds = kXNB * kXTile + 4 * kMelHPlane * 2 + 2 * 8 * 32 * 4 + kXExch;
+static_assert(kCXLds + 256 <= 160 * 1024, "LDS budget of cnn2x_kernel");
+
+// OUT 1: out = pooled [n][64].
+template <int OUT>
+__global__ __launch_bounds__(768, 3) void cnn2x_kernel(const float* __restrict__ mel, int n, int width,
+                                                       const u32x4* __restrict__ w1H, const float* __restrict__ hs1,
+                                                       const float* __restrict__ b1,
+                                                       const u32x4* __restrict__ wX, const float* __restrict__ hs,
+                                                       const float* __restrict__ b2, const float* __restrict__ rng,
+                                                       float* __restrict__ out) {
+    static_assert(OUT == 1, "only the pooled form is built");
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char* act0 = ldsb;
+    _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + kXNB * kXTile);      // 2 clips x (hi plane, lo plane) of [82][36] f16
+    float* red = reinterpret_cast<float*>(melh0 + 4 * kMelHPlane);           // [clip parity][8 consumer waves][32]
+    char* exch = reinterpret_cast<char*>(red + 2 * 8 * 32);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 8;
+    const int ptid = tid - 512;
+
+    __shared__ uint32_t full_cnt[kXNB], free_cnt[kXNB], xfull[4][2], xfree[4][2], mel_done, xmax_done, clip_done[2], wg_bad;
+    __shared__ float xmaxw[2][4];
+    __shared__ float clip_par[2][2];
+    if (tid < kXNB) { full_cnt[tid] = 0u; free_cnt[tid] = 0u; }
+    if (tid < 8) { xfull[tid >> 1][tid & 1] = 0u; xfree[tid >> 1][tid & 1] = 0u; }
+    if (tid == 0) { mel_done = 0u; xmax_done = 0u; clip_done[0] = 0u; clip_done[1] = 0u; wg_bad = 0u; }
+    for (int i = tid; i < kCXLds / 4; i += 768) reinterpret_cast<uint32_t*>(ldsb)[i] = 0u;   // column halos / dead columns stay zero
+    __syncthreads();
+
+    const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
+#ifdef WW_STAMPS
+    unsigned long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clast = 0;
+    CSTAMP(7);
+#endif
+
+    if (!consumer) {
+        // ================================================= producers =================================================
+        const int pw = wave - 8;
+        u32x4 w1h_r = w1H[lane], w1l_r = w1H[64 + lane];
+        asm volatile("" : "+v"(w1h_r), "+v"(w1l_r));
+        const half8 a1h = __builtin_bit_cast(half8, w1h_r), a1l = __builtin_bit_cast(half8, w1l_r);
+        const GatherLanes glanes = gather_lanes(lane & 31, lane >> 5);
+        __builtin_amdgcn_s_setprio(WW_WINO_PPRIO);
+        const float rng_l1 = rng[0], rng_b1 = rng[1];
+        const int s1_exp = -exp_of(hs1[0]);
+        auto load_mel = [&](int k, int& e_out, int& a_out) {      // as in cnn2w_kernel
+            const float* __restrict__ src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kH * width;
+            _Float16* ph = melh0 + (k & 1) * 2 * kMelHPlane;
+            const int xx = ptid & 31, y0 = ptid >> 5;
+            const bool col_live = xx < width;
+            const float* __restrict__ sp = src + y0 * width + xx;
+            float v[10];
+            float mx = 0.f;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                v[t] = col_live ? sp[8 * t * width] : 0.f;
+                mx = fmaxf(mx, __builtin_fabsf(v[t]));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            if (lane == 0) xmaxw[k & 1][pw] = mx;
+            flag_signal(&xmax_done);
+            flag_wait(&xmax_done, 4u * unsigned(k + 1), &wg_bad);
+            mx = fmaxf(fmaxf(xmaxw[k & 1][0], xmaxw[k & 1][1]), fmaxf(xmaxw[k & 1][2], xmaxw[k & 1][3]));
+            const int e = clampi(exp_of(mx) - 14, -100, 113);
+            const float bound1 = fmaf(mx, rng_l1, rng_b1);
+            const int a = clampi(exp_of(bound1) - 12, -100, 100);
+            if (tid == 512) { clip_par[k & 1][0] = pow2i(a); clip_par[k & 1][1] = bound1; }
+            const float down = pow2i(-e);
+            if (col_live) {
+                _Float16* dh = ph + (y0 + 1) * kMelHRS + xx + 1;
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    const float vv = v[t] * down;
+                    const _Float16 hi = static_cast<_Float16>(vv);
+                    dh[8 * t * kMelHRS] = hi;
+                    dh[8 * t * kMelHRS + kMelHPlane] = static_cast<_Float16>(vv - static_cast<float>(hi));
+                }
+            }
+            e_out = e;
+            a_out = a;
+        };
+        Conv1Scale cs;
+        auto set_conv1_scale = [&](int e, int a) {
+            const int c0 = 16 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cs.binit[j] = ldexpf(b1[c0 + j], s1_exp - e);
+            cs.sc = ldexpf(1.0f, e - a - s1_exp);
+        };
+        const int x = lane & 31, h = lane >> 5;
+        const bool col_ok = x < width;
+        // this lane's 16 channels 16 h .. 16 h + 15 are chunks 2 h and 2 h + 1 of position x + 1 (swizzled)
+        const int wr0 = (x + 1) * kXRec + (((2 * h) ^ (((x + 1) >> 2) & 3)) << 4);
+        auto store16 = [&](const f32x16& v, char* plane) {     // plane: the hi half of one of the four planes of a tile row
+#pragma unroll
+            for (int g8 = 0; g8 < 2; ++g8) {
+                u32x4 vh, vl;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t hh, ll;
+                    split2(v[8 * g8 + 2 * d], v[8 * g8 + 2 * d + 1], hh, ll);
+                    vh[d] = hh;
+                    vl[d] = ll;
+                }
+                char* rec = plane + (wr0 ^ (g8 << 4));
+                *reinterpret_cast<u32x4*>(rec) = vh;
+                *reinterpret_cast<u32x4*>(rec + kXPlane) = vl;
+            }
+        };
+        int e_nx = 0, a_nx = 0;
+        if (my_clips > 0) { load_mel(0, e_nx, a_nx); flag_signal(&mel_done); }
+        const int pgrp = pw >> 1, podd = pw & 1;
+        f32x16 d0, d1, d2, d3;
+        auto conv1_rows2 = [&](const _Float16* plane, int ya, f32x16& ra, f32x16& rb) {
+            Conv1Row r0, r1;
+            const bool va = unsigned(ya) < unsigned(kH), vb = unsigned(ya + 1) < unsigned(kH);
+            conv1_row_gather(r0, plane, glanes, va ? ya : (ya < 0 ? 0 : kH - 1));
+            conv1_row_gather(r1, plane, glanes, vb ? ya + 1 : (ya + 1 < 0 ? 0 : kH - 1));
+            conv1_row_mfma(r0, a1h, a1l, cs);
+            conv1_row_mfma(r1, a1h, a1l, cs);
+            const float sa = va ? cs.sc : 0.f, sb = vb ? cs.sc : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                ra[j] = relu2(r0.acc[j] * sa);
+                rb[j] = relu2(r1.acc[j] * sb);
+            }
+        };
+        for (int k = 0; k < my_clips; ++k) {
+            flag_wait(&mel_done, 4u * unsigned(k + 1), &wg_bad);
+            set_conv1_scale(e_nx, a_nx);
+            if (k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
+            const _Float16* plane = melh0 + (k & 1) * 2 * kMelHPlane;
+#pragma unroll 1
+            for (int i = 0; i < kWPerProd; ++i) {
+                const int t = kWPerProd * pw + i;
+                const int q = k * kWPerGroup + 2 * i + podd;
+                const int b = pgrp * kWRing + q % kWRing;
+                CSTAMP(0);
+#ifndef WW_ABL_NOPROD
+                if (i == 0) conv1_rows2(plane, 2 * t - 1, d0, d1);
+                else { d0 = d2; d1 = d3; }
+                conv1_rows2(plane, 2 * t + 1, d2, d3);
+#endif
+#ifdef WW_STAMPS
+                asm volatile("" :: "v"(d2[0]), "v"(d3[15]));
+#endif
+                CSTAMP(1);
+                flag_wait(&free_cnt[b], 4u * unsigned(q / kWRing), &wg_bad);
+                CSTAMP(2);
+#ifndef WW_ABL_NOPROD
+                if (col_ok) {
+                    char* tile = act0 + b * kXTile;
+                    store16(d1 + d2, tile);                      // plane 0 = V1
+                    store16(d0 - d2, tile + 2 * kXPlane);        // plane 1 = V0
+                    store16(d2 - d1, tile + 4 * kXPlane);        // plane 2 = V2
+                    store16(d1 - d3, tile + 6 * kXPlane);        // plane 3 = V3
+                }
+#endif
+                flag_signal(&full_cnt[b]);
+                CSTAMP(3);
+            }
+        }
+    } else {
+        // ================================================= consumers =================================================
+        const int nt = wave & 1, xh = (wave >> 1) & 1, grp = wave >> 2;
+        const int pair = 2 * grp + nt;
+        const int r = lane & 31, hh = lane >> 5;
+        // B operands: the wave's two xi (first = the one it gives away: 1 | 2, second: 0 | 3), steps s = dx * 2 + c
+        const int xi_f = xh ? 2 : 1, xi_s = xh ? 3 : 0;
+        half8 bfh[6], bfl[6], bsh[6], bsl[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            bfh[s] = __builtin_bit_cast(half8, wX[(((nt * 4 + xi_f) * 6 + s) * 2 + 0) * 64 + lane]);
+            bfl[s] = __builtin_bit_cast(half8, wX[(((nt * 4 + xi_f) * 6 + s) * 2 + 1) * 64 + lane]);
+            bsh[s] = __builtin_bit_cast(half8, wX[(((nt * 4 + xi_s) * 6 + s) * 2 + 0) * 64 + lane]);
+            bsl[s] = __builtin_bit_cast(half8, wX[(((nt * 4 + xi_s) * 6 + s) * 2 + 1) * 64 + lane]);
+        }
+        const float bias = b2[32 * nt + r];
+        const float descale = 0.5f * hs[32 * nt + r];
+        float dsc = descale, pool = 0.f;
+        const float sg = xh ? -1.f : 1.f;
+        // fragment offsets inside a (plane, half): step (dx, c): position r + dx, chunk 2 c + hh, swizzled
+        int fo[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int dx = s >> 1, c = s & 1, p = r + dx;
+            fo[s] = p * kXRec + (((2 * c + hh) ^ ((p >> 2) & 3)) << 4) + 4 * xh * kXPlane;     // the wave's planes 2 xh, 2 xh + 1
+        }
+        char* xw = exch + (pair * 2 + xh) * 4096 + lane * 16;             // what this wave gives
+        const char* xr = exch + (pair * 2 + (xh ^ 1)) * 4096 + lane * 16;  // what it takes
+        const int gsteps = my_clips * kWPerGroup;
+        CLK_BEGIN();
+        for (int q = 0; q < gsteps; ++q) {
+            const int k = q / kWPerGroup, sq = q - k * kWPerGroup;
+            const int b = grp * kWRing + q % kWRing;
+            CSTAMP(0);
+            flag_wait(&full_cnt[b], unsigned(q / kWRing) + 1u, &wg_bad);
+            CSTAMP(1);
+            if (sq == 0) {
+                dsc = descale * clip_par[k & 1][0];
+                pool = 0.f;
+            }
+            const char* tile = act0 + b * kXTile;
+            f32x16 accf, accs;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { accf[j] = 0.f; accs[j] = 0.f; }
+            // 12 fragment steps: it < 6 the first xi (plane 2 xh), then the second (plane 2 xh + 1)
+            auto frag = [&](int it, int half) -> half8 {
+                const int sel = it / 6, s = it % 6;
+                return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(tile + fo[s] + (2 * sel + half) * kXPlane));
+            };
+#ifndef WW_X32_PF
+#define WW_X32_PF 1
+#endif
+            constexpr int PF = WW_X32_PF, RING = PF + 1;
+            half8 fh[RING], fl[RING];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) { fh[i] = frag(i, 0); fl[i] = frag(i, 1); }
+#ifdef WW_ABL_NOCONS           // timing-only ablation: producers alone (no MFMAs, no exchange)
+#define WW_ABL_X_NOXCH
+            constexpr int kIts = 0;
+#else
+            constexpr int kIts = 12;
+#endif
+#pragma unroll
+            for (int it = 0; it < kIts; ++it) {
+                if (it + PF < 12) { fh[(it + PF) % RING] = frag(it + PF, 0); fl[(it + PF) % RING] = frag(it + PF, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const half8 ah = fh[it % RING], al = fl[it % RING];
+                if (it < 6) {
+                    accf = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bfh[it], accf, 0, 0, 0);
+                    accf = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bfl[it], accf, 0, 0, 0);
+                    accf = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bfh[it], accf, 0, 0, 0);
+                } else {
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bsh[it - 6], accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bsl[it - 6], accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bsh[it - 6], accs, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef WW_ABL_X_NOXCH      // timing-only ablation: no exchange at all (results are garbage)
+                if (it == 7) {
+                    // the first accumulator is complete: give it to the partner (who read the slot's previous content at the end of ITS
+                    // previous tile row) while the second xi's MFMAs run
+                    CSTAMP(2);
+#ifndef WW_ABL_X_NOWAIT     // timing-only ablation: the exchange without its waits
+                    flag_wait(&xfree[pair][xh], unsigned(q), &wg_bad);
+#endif
+                    CSTAMP(3);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = {accf[4 * i], accf[4 * i + 1], accf[4 * i + 2], accf[4 * i + 3]};
+                        *reinterpret_cast<f32x4*>(xw + i * 1024) = v;
+                    }
+                    flag_signal(&xfull[pair][xh]);
+                    CSTAMP(4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
+            }
+            CSTAMP(2);
+            flag_signal(&free_cnt[b]);                       // the buffer is free as soon as its fragments are in the accumulators
+            CSTAMP(5);
+            // the partner's accumulator; then this wave's output row: A (xh 0): row 2t = M0 + (M1 + M2); B: row 2t + 1 = (M1 - M2) - M3
+#if !defined(WW_ABL_X_NOWAIT) && !defined(WW_ABL_X_NOXCH)
+            flag_wait(&xfull[pair][xh ^ 1], unsigned(q) + 1u, &wg_bad);
+#endif
+            CSTAMP(6);
+            f32x16 oth;
+#ifndef WW_ABL_X_NOXCH
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i * 1024);
+                oth[4 * i] = v[0]; oth[4 * i + 1] = v[1]; oth[4 * i + 2] = v[2]; oth[4 * i + 3] = v[3];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flag_signal(&xfree[pair][xh ^ 1]);
+#else
+#pragma unroll
+            for (int j = 0; j < 16; ++j) oth[j] = bias;
+#endif
+            // one instruction stream for both: y = sg accs + (sg accf + oth), sg = +1 (A) | -1 (B); an fma by +-1 rounds once, like the add
+            float pv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float y = fmaf(sg, accs[j], fmaf(sg, accf[j], oth[j]));
+                pv[j] = relu2(fmaf(y, dsc, bias));
+            }
+            if (width != kW) {                       // wave-uniform; D: register j <-> column (j & 3) + 8 (j >> 2) + 4 hh
+#pragma unroll
+                for (int j = 0; j < 16; ++j) pv[j] = (j & 3) + 8 * (j >> 2) + 4 * hh < width ? pv[j] : 0.f;
+            }
+            pool += tree16(pv);
+            if (sq == kWPerGroup - 1) {               // this wave's last tile row of the clip
+                const float p2 = pool + __shfl_xor(pool, 32);
+                float* rk = red + (k & 1) * 8 * 32;
+                if (lane < 32) rk[wave * 32 + lane] = p2;
+                // the last of the eight consumer waves to arrive writes the clip's pooled features
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                uint32_t old = 0u;
+                if (lane == 0) old = __hip_atomic_fetch_add(&clip_done[k & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old + 1u == 8u * unsigned(k / 2 + 1)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                    const int ln = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+                    const float scale = 0.5f / float(kH * __builtin_amdgcn_readfirstlane(width));
+                    // channel ln = 32 nt + r: waves nt + 2 xh + 4 g; fixed order (rows 2t, 2t+1 of group 0, then of group 1)
+                    const float* w0 = rk + (ln >> 5) * 32 + (ln & 31);
+                    out[clip * 64 + ln] = ((w0[0] + w0[2 * 32]) + (w0[4 * 32] + w0[6 * 32])) * scale;
+                }
+            }
+        }
+        CLK_END();
+    }
+#ifdef WW_STAMPS
+    CSTAMP(7);
+    if (lane == 0 && blockIdx.x == 7 && (wave == 1 || wave == 9))
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_cnn_stamps[i + (wave == 9 ? 8 : 0)], cst[i]);
+#endif
+    // an expired wait anywhere in this workgroup: poison everything it produced
+    __syncthreads();
+    if (__hip_atomic_load(&wg_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+        const float nan = __uint_as_float(0x7fc00000u);
+        for (int k = 0; k < my_clips; ++k) {
+            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+            if (tid < 64) out[clip * 64 + tid] = nan;
         }
     }
 }
@@ -1441,6 +1822,7 @@ static int opt_in_lds() {
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kC3wLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2w_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kCWLds));
+    WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn2x_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kCXLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kC3hLds));
     WW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                int(sizeof(float) * kC3LdsFloats)));
@@ -1534,6 +1916,16 @@ int launch_cnn_pool(const float* mel, int64_t n, int width, const float* packed,
         const u32x4* w2h = reinterpret_cast<const u32x4*>(packed + L.conv2_h16);
         if (cmath == 1) {                                      // conv2 (and conv3) as 1-D Winograd
             const u32x4* w2w = reinterpret_cast<const u32x4*>(packed + L.conv2_hw);
+#ifndef WW_K2_X32
+#define WW_K2_X32 0        // 1: conv2 of the 2-conv model on v_mfma_f32_32x32x16_f16 (cnn2x_kernel); 0: cnn2w_kernel (16x16x32), the round-3 form
+#endif
+            if (n_conv == 2 && WW_K2_X32) {
+                hipLaunchKernelGGL(cnn2x_kernel<1>, dim3(grid1), dim3(768), kCXLds, stream, mel, int(n), width, w1h,
+                                   packed + L.conv1_hs, packed + L.conv1_b, reinterpret_cast<const u32x4*>(packed + L.conv2_hx),
+                                   packed + L.conv2_hws, packed + L.conv2_b, packed + L.range, pooled);
+                WW_HIP(hipGetLastError());
+                return WW_OK;
+            }
             if (n_conv == 2) {
                 hipLaunchKernelGGL(cnn2w_kernel<true>, dim3(grid1), dim3(768), kCWLds, stream, mel, int(n), width, w1h,
                                    packed + L.conv1_hs, packed + L.conv1_b, w2w, packed + L.conv2_hws, packed + L.conv2_b,

@@ -101,6 +101,7 @@ struct PackedLayout {
     int64_t conv2_hws; // [64]: 2^-S per output channel of the transformed weights
     int64_t conv3_hw;  // (n_conv 3) conv3 in the same Winograd form: [8 ntile][24 kstep = (xi*3+dx)*2 + cb][hi,lo][64 lanes][4 dwords]
     int64_t conv3_hws; // [128]
+    int64_t conv2_hx;  // conv2 in the same Winograd form as B operands of v_mfma_f32_32x32x16_f16 (cnn2x_kernel): [2 ntile][4 xi][6 step = dx*2 + c][hi,lo][64 lanes][4 dwords]; scales = conv2_hws
     int64_t range;     // [8]: l1 bound of conv1 (max over channels of sum |w|), max |b1|, the same for conv2, 0...
     int64_t total;
 };

@@ -192,6 +192,7 @@ PackedLayout packed_layout(int n_conv) {
     L.conv3_hw = n_conv == 3 ? take(8 * 24 * 2 * 64 * 4) : -1;
     L.conv3_hws = n_conv == 3 ? take(128) : -1;
     L.range = take(8);
+    L.conv2_hx = take(2 * 4 * 6 * 2 * 64 * 4);
     L.total = o;
     return L;
 }
@@ -320,6 +321,43 @@ static void pack_conv_wino_f16x3(const float* w, int cout, int cin, float* out_w
                             o16[base + 64 * 8 + lane * 8 + j] = lb;
                         }
                 }
+}
+
+// conv2 weight [64][32][3][3] -> the same Winograd form (same U, same per-channel scales as pack_conv_wino_f16x3: `descale` is shared)
+// as B operands of v_mfma_f32_32x32x16_f16 for cnn2x_kernel: N-tile nt = 32 output channels, k-step s = dx*2 + c covers input channels
+// 16 c .. 16 c + 15 of tap dx; lane (n = lane&31, hh = lane>>5) holds B[k = 8 hh + j][n] = U_xi[dx][16 c + 8 hh + j][32 nt + n] * 2^S[co]:
+// out[nt][xi][s][hi, lo][64 lanes][4 dwords].
+static void pack_conv2_wino_x32_f16x3(const float* w, float* out_words) {
+    const int cout = 64, cin = 32;
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out_words);
+    for (int co = 0; co < cout; ++co) {
+        double U[32][4][3];
+        double m = 0.0;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int dx = 0; dx < 3; ++dx) {
+                const double w0 = w[((co * cin + ci) * 3 + 0) * 3 + dx], w1 = w[((co * cin + ci) * 3 + 1) * 3 + dx],
+                             w2 = w[((co * cin + ci) * 3 + 2) * 3 + dx];
+                U[ci][0][dx] = w0;
+                U[ci][1][dx] = 0.5 * (w0 + w1 + w2);
+                U[ci][2][dx] = 0.5 * (w0 - w1 + w2);
+                U[ci][3][dx] = w2;
+                for (int xi = 0; xi < 4; ++xi) m = std::fmax(m, std::fabs(U[ci][xi][dx]));
+            }
+        const int S = scale_exp(float(m) * 1.0000001f);
+        const int nt = co >> 5, n = co & 31;
+        for (int xi = 0; xi < 4; ++xi)
+            for (int dx = 0; dx < 3; ++dx)
+                for (int c = 0; c < 2; ++c)
+                    for (int hh = 0; hh < 2; ++hh)
+                        for (int j = 0; j < 8; ++j) {
+                            uint16_t hb, lb;
+                            split_f16(std::ldexp(U[16 * c + 8 * hh + j][xi][dx], S), hb, lb);
+                            const int lane = 32 * hh + n;
+                            const int64_t base = ((((int64_t(nt) * 4 + xi) * 6 + dx * 2 + c) * 2) * 64) * 8;      // in f16 units
+                            o16[base + lane * 8 + j] = hb;
+                            o16[base + 64 * 8 + lane * 8 + j] = lb;
+                        }
+    }
 }
 
 // conv3 weight [128][64][3][3] -> split-precision f16 B operands for v_mfma_f32_16x16x32_f16:
@@ -477,6 +515,7 @@ int ww_pack_weights_host(const ww_state_dict* sd, float* out) {
     pack_conv1_f16x3(sd->conv_weight[0], out + L.conv1_h, out + L.conv1_hs);
     pack_conv2_f16x3(sd->conv_weight[1], out + L.conv2_h16, out + L.conv2_hs);
     pack_conv_wino_f16x3(sd->conv_weight[1], 64, 32, out + L.conv2_hw, out + L.conv2_hws);
+    pack_conv2_wino_x32_f16x3(sd->conv_weight[1], out + L.conv2_hx);
     if (sd->n_conv == 3) pack_conv_wino_f16x3(sd->conv_weight[2], 128, 64, out + L.conv3_hw, out + L.conv3_hws);
     pack_lstm_f16x3(sd->lstm_weight_ih[0], L.c_last, out + L.l0_h, out + L.lstm_hs);
     pack_lstm_f16x3(sd->lstm_weight_ih[1], kHidden, out + L.l1_h, out + L.lstm_hs + kGateCols);
