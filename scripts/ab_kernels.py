@@ -70,7 +70,11 @@ for path, h, pk in zip(libs, hs, packs):
     got = {"logmel": out, "head": lg, "full": lg, "full3": lg}.get(what, pooled).clone()
     if first is None:
         first = got
-    print("%-40s max |diff| vs first build %.3g" % (path.split("/")[-1], float((got - first).abs().max())))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): run(h, pk)
+    torch.cuda.synchronize()
+    print("%-40s max |diff| vs first build %.3g   (first look: %.4f ms)" % (path.split("/")[-1], float((got - first).abs().max()),
+                                                                           (time.perf_counter() - t0) * 200), flush=True)
 for rnd in range(12):
     for p, h, pk in zip(libs, hs, packs):
         torch.cuda.synchronize(); t = time.perf_counter()

@@ -79,6 +79,9 @@ __device__ __forceinline__ void conv1_row_mfma(Conv1Row& r, half8 a1h, half8 a1l
     r.acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, r.ph, r.acc, 0, 0, 0);
 }
 
+#ifndef WW_SPLIT_MIX
+#define WW_SPLIT_MIX 1
+#endif
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
@@ -89,9 +92,18 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     const half2_t h = __builtin_convertvector(v, half2_t);
     // a - float(hi) as one mixed-precision fma per value (v_fma_mix_f32 reads the f16 half directly, exact like the subtraction):
     // 4 instructions per pair instead of 5 with a half-rate packed subtract (bit-identical, -3 % on the conv kernel)
-    const float2_t r = {__builtin_fmaf(static_cast<float>(h[0]), -1.0f, a), __builtin_fmaf(static_cast<float>(h[1]), -1.0f, b)};
-    const half2_t l = __builtin_convertvector(r, half2_t);
     hi = __builtin_bit_cast(uint32_t, h);
+#if WW_SPLIT_MIX
+    // round 4: hipcc lowers the two fmas above to v_cvt_f32_f16 + v_sub_f32 each (6 instructions per pair); written out, v_fma_mix_f32 reads
+    // the f16 half straight from the packed register (op_sel picks the half, op_sel_hi marks it as f16): 4 per pair, same bits
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(b));
+    const float2_t r = {r0, r1};
+#else
+    const float2_t r = {__builtin_fmaf(static_cast<float>(h[0]), -1.0f, a), __builtin_fmaf(static_cast<float>(h[1]), -1.0f, b)};
+#endif
+    const half2_t l = __builtin_convertvector(r, half2_t);
     lo = __builtin_bit_cast(uint32_t, l);
 }
 
