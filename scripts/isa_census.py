@@ -107,7 +107,7 @@ def main():
         return
     ranges = a.range or [f"all:1:{len(kl)}"]
     for r in ranges:
-        name, lo, hi = r.split(":")
+        name, lo, hi = r.rsplit(":", 2)
         c, d = census(kl[int(lo) - 1:int(hi)])
         ic = issue_cycles(c, d)
         print(f"== {name} (lines {lo}-{hi})")

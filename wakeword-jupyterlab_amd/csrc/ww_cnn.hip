@@ -357,18 +357,6 @@ __device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t target, uint32_t
     }
 }
 
-// A wait whose counter was READ EARLIER (flag_peek, issued a few MFMA steps before the value is needed, so that the LDS round trip of
-// the poll is not on the wave's critical path): the counters are monotonic, so a stale value that already meets the target is proof
-// enough; otherwise fall back to the polling wait.
-__device__ __forceinline__ uint32_t flag_peek(uint32_t* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void flag_wait_peeked(uint32_t seen, uint32_t* f, uint32_t target, uint32_t* bad) {
-    if (__builtin_amdgcn_readfirstlane(seen) >= target) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        return;
-    }
-    flag_wait(f, target, bad);
-}
-
 #ifdef WW_STAMPS
 __device__ unsigned long long g_cnn_stamps[16];
 #define CSTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
@@ -799,9 +787,6 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
 #ifndef WW_WINO_PPRIO
 #define WW_WINO_PPRIO 3
 #endif
-#ifndef WW_MEL_MID
-#define WW_MEL_MID 0
-#endif
         __builtin_amdgcn_s_setprio(WW_WINO_PPRIO);
         const float rng_l1 = rng[0], rng_b1 = rng[1];
         const int s1_exp = -exp_of(hs1[0]);
@@ -891,18 +876,10 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
         for (int k = 0; k < my_clips; ++k) {
             flag_wait(&mel_done, 4u * unsigned(k + 1), &wg_bad);              // the clip's planes are complete
             set_conv1_scale(e_nx, a_nx);
-#if !WW_MEL_MID
             if (k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
-#endif
             const _Float16* plane = melh0 + (k & 1) * 2 * kMelHPlane;
 #pragma unroll 1
             for (int i = 0; i < kWPerProd; ++i) {
-#if WW_MEL_MID
-                // the next clip's planes are loaded in the MIDDLE of this clip (round 4): at the clip boundary the load's latency and the
-                // producers' meeting inside it stopped the supply of tile rows for longer than the ring holds, once per clip; here the
-                // producers are ahead of the consumers and the time comes out of their wait for a free buffer
-                if (i == 4 && k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
-#endif
                 const int t = kWPerProd * pw + i;
                 const int q = k * kWPerGroup + 2 * i + podd;                  // position in the group's sequence of tile rows
                 const int b = pgrp * kWRing + q % kWRing;
@@ -955,169 +932,6 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
 #endif
         const int gsteps = my_clips * kWPerGroup;
         CLK_BEGIN();
-#ifndef WW_WINO_PIPE
-#define WW_WINO_PIPE 0
-#endif
-#if WW_WINO_PIPE
-        // Round 4: the consumer loop as a software pipeline.  A tile row's 24 fragment steps run column half by column half (c = 0: steps
-        // 0-11 into accA, c = 1: steps 12-23 into accB), and the output transform + bias + 2 relu + pool of a finished half is issued in
-        // QUARTERS (one accumulator register j each) between the MFMA steps of the NEXT half -- accB of tile row q - 1 under the c = 0
-        // steps of tile row q, accA of tile row q under its own c = 1 steps -- instead of as one block between two tile rows; the
-        // counter of the next tile row's buffer is read (flag_peek) three steps before the tile row ends.  Same values, same order of
-        // additions as the plain loop (pool += tree4(half 0) + tree4(half 1) per tile row).
-        auto fin_quarter = [&](const f32x4 (&a)[4], int c, int j, float dsc_f, int k_f, int trow_f, float& pvj, unsigned long long& l0,
-                               unsigned long long& l1) {
-            const float m12 = a[1][j] + a[2][j], m1m2 = a[1][j] - a[2][j];
-            const float y0 = a[0][j] + m12, y1 = m1m2 - a[3][j];
-            const float v0 = relu2(fmaf(y0, dsc_f, bias)), v1 = relu2(fmaf(y1, dsc_f, bias));
-            const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
-            if constexpr (POOL) {
-                pvj = col_live ? v0 + v1 : 0.f;
-            } else {
-                const int64_t clip = int64_t(blockIdx.x) + int64_t(k_f) * gridDim.x;
-                float* o = out + ((clip * kH + 2 * trow_f) * kW + 16 * c + 4 * kq + j) * 64 + 16 * nt + pi;
-                o[0] = col_live ? 0.5f * v0 : 0.f;
-                o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
-            }
-            if constexpr (BITS) {       // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
-                l0 = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
-                l1 = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
-            }
-        };
-        auto bits_out = [&](const unsigned long long (&live0)[4], const unsigned long long (&live1)[4], int c, int k_f, int trow_f) {
-            if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
-                uint32_t word = 0u;
-                word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
-                word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
-                word = write_lane<4>(uint32_t(live0[2]), word);  word = write_lane<5>(uint32_t(live0[2] >> 32), word);
-                word = write_lane<6>(uint32_t(live0[3]), word);  word = write_lane<7>(uint32_t(live0[3] >> 32), word);
-                word = write_lane<8>(uint32_t(live1[0]), word);  word = write_lane<9>(uint32_t(live1[0] >> 32), word);
-                word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
-                word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
-                word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
-                if (lane < 16) {
-                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k_f) * gridDim.x;
-                    reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow_f) * 4 + nt) * 2 + c) * 16) + lane] = word;
-                }
-            }
-        };
-        auto clip_end = [&](int k_f) {     // this wave's share of the clip's pooled features is complete
-            if constexpr (POOL) {
-                float p2 = pool + __shfl_xor(pool, 16);
-                p2 += __shfl_xor(p2, 32);
-                float* rk = red + (k_f & 1) * 8 * 16;
-                if (lane < 16) rk[wave * 16 + lane] = p2;
-                // the last of the eight consumer waves to arrive writes the clip's pooled features
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                uint32_t old = 0u;
-                if (lane == 0) old = __hip_atomic_fetch_add(&clip_done[k_f & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                old = __builtin_amdgcn_readfirstlane(old);
-                if (old + 1u == 8u * unsigned(k_f / 2 + 1)) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k_f) * gridDim.x;
-                    const int ln = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-                    const float scale = 0.5f / float(kH * __builtin_amdgcn_readfirstlane(width));
-                    out[clip * 64 + ln] = (rk[ln] + rk[64 + ln]) * scale;
-                }
-                pool = 0.f;
-            }
-        };
-        f32x4 accA[4], accB[4];
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { accA[xi][j] = 0.f; accB[xi][j] = 0.f; }
-        uint32_t pk = gsteps > 0 ? flag_peek(&full_cnt[grp * kWRing]) : 0u;
-        int k_p = 0, trow_p = 0;             // the tile row whose c = 1 half (accB) is still to be finished
-        float dsc_p = descale, t0 = 0.f;     // its descale; tree4 of its c = 0 half
-        for (int q = 0; q < gsteps; ++q) {
-            const int k = q / kWPerGroup, sq = q - k * kWPerGroup;
-            const int b = grp * kWRing + q % kWRing;
-            flag_wait_peeked(pk, &full_cnt[b], unsigned(q / kWRing) + 1u, &wg_bad);
-            if (sq == 0) {
-                dsc = descale * clip_par[k & 1][0];
-                if constexpr (!POOL) {
-                    if (wave == 0 && lane == 0) {     // |V3| <= 2 max relu(conv2): one more bit of headroom than a plain split needs
-                        const float bound2 = fmaf(clip_par[k & 1][1], rng[2], rng[3]);
-                        apow2[int64_t(blockIdx.x) + int64_t(k) * gridDim.x] = pow2i(clampi(exp_of(bound2) - 13, -100, 100));
-                    }
-                }
-            }
-            const int trow = kWPerProd * (2 * grp + (sq & 1)) + (sq >> 1);      // the tile row this step holds (producer 2 grp + (sq & 1), its i-th)
-            const char* ap = act0 + b * kWBuf + pi * kWRec + kq * 16;
-            // 24 fragment steps it = c*12 + dx*4 + xi: consecutive steps hit different accumulators
-            auto frag = [&](int it, int half) -> half8 {
-                const int c = it / 12, dx = (it % 12) >> 2, xi = it & 3;
-                return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(ap + xi * kWPlane + (16 * c + dx) * kWRec + half * 64));
-            };
-#ifndef WW_WINO_PF
-#define WW_WINO_PF 2
-#endif
-            constexpr int PF = WW_WINO_PF, RING = PF + 1;
-            half8 fh[RING], fl[RING];
-#pragma unroll
-            for (int i = 0; i < PF; ++i) { fh[i] = frag(i, 0); fl[i] = frag(i, 1); }
-            float pvq[4] = {0.f, 0.f, 0.f, 0.f};
-            unsigned long long live0[4] = {0, 0, 0, 0}, live1[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int it = 0; it < 24; ++it) {
-                if (it + PF < 24) { fh[(it + PF) % RING] = frag(it + PF, 0); fl[(it + PF) % RING] = frag(it + PF, 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                const half8 ah = fh[it % RING], al = fl[it % RING];
-                const int c = it / 12, dx = (it % 12) >> 2, xi = it & 3;
-                const int ks = xi * 3 + dx;
-                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                if (c == 0) {
-                    accA[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], dx == 0 ? zero4 : accA[xi], 0, 0, 0);
-                    accA[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], accA[xi], 0, 0, 0);
-                    accA[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], accA[xi], 0, 0, 0);
-                } else {
-                    accB[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], dx == 0 ? zero4 : accB[xi], 0, 0, 0);
-                    accB[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], accB[xi], 0, 0, 0);
-                    accB[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], accB[xi], 0, 0, 0);
-                }
-                // the finished half under these steps: quarters after steps 1, 3, 5, 7 of a half (accB is rewritten from step 12 on,
-                // accA from step 0 of the next tile row on), its sums after step 9
-                const int r = it % 12;
-                if (c == 0 && q > 0) {
-                    if (r == 1 || r == 3 || r == 5 || r == 7) {
-                        const int j = (r - 1) >> 1;
-                        fin_quarter(accB, 1, j, dsc_p, k_p, trow_p, pvq[j], live0[j], live1[j]);
-                    }
-                    if (r == 9) {
-                        bits_out(live0, live1, 1, k_p, trow_p);
-                        if constexpr (POOL) pool += t0 + tree4(pvq[0], pvq[1], pvq[2], pvq[3]);
-                        if (sq == 0) clip_end(k_p);                                   // the pending tile row was its clip's last
-                    }
-                }
-                if (c == 1) {
-                    if (r == 1 || r == 3 || r == 5 || r == 7) {
-                        const int j = (r - 1) >> 1;
-                        fin_quarter(accA, 0, j, dsc, k, trow, pvq[j], live0[j], live1[j]);
-                    }
-                    if (r == 8) pk = flag_peek(&full_cnt[grp * kWRing + (q + 1) % kWRing]);
-                    if (r == 9) {
-                        bits_out(live0, live1, 0, k, trow);
-                        if constexpr (POOL) t0 = tree4(pvq[0], pvq[1], pvq[2], pvq[3]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#ifndef WW_ABL_X_NORING
-            flag_signal(&free_cnt[b]);                       // the buffer is free as soon as its fragments are in the accumulators
-#endif
-            k_p = k; trow_p = trow; dsc_p = dsc;
-        }
-        if (gsteps > 0) {                                   // the last tile row's c = 1 half
-            float pvq[4] = {0.f, 0.f, 0.f, 0.f};
-            unsigned long long live0[4] = {0, 0, 0, 0}, live1[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fin_quarter(accB, 1, j, dsc_p, k_p, trow_p, pvq[j], live0[j], live1[j]);
-            bits_out(live0, live1, 1, k_p, trow_p);
-            if constexpr (POOL) pool += t0 + tree4(pvq[0], pvq[1], pvq[2], pvq[3]);
-            clip_end(k_p);
-        }
-#else
         for (int q = 0; q < gsteps; ++q) {
             const int k = q / kWPerGroup, sq = q - k * kWPerGroup;
             const int b = grp * kWRing + q % kWRing;
@@ -1244,7 +1058,6 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                 }
             }
         }
-#endif
         CLK_END();
     }
     // an expired wait anywhere in this workgroup: poison everything it produced (pooled features, or the conv3 scale)
@@ -1417,18 +1230,10 @@ __global__ __launch_bounds__(768, 3) void cnn2x_kernel(const float* __restrict__
         for (int k = 0; k < my_clips; ++k) {
             flag_wait(&mel_done, 4u * unsigned(k + 1), &wg_bad);
             set_conv1_scale(e_nx, a_nx);
-#if !WW_MEL_MID
             if (k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
-#endif
             const _Float16* plane = melh0 + (k & 1) * 2 * kMelHPlane;
 #pragma unroll 1
             for (int i = 0; i < kWPerProd; ++i) {
-#if WW_MEL_MID
-                // the next clip's planes are loaded in the MIDDLE of this clip (round 4): at the clip boundary the load's latency and the
-                // producers' meeting inside it stopped the supply of tile rows for longer than the ring holds, once per clip; here the
-                // producers are ahead of the consumers and the time comes out of their wait for a free buffer
-                if (i == 4 && k + 1 < my_clips) { load_mel(k + 1, e_nx, a_nx); flag_signal(&mel_done); }
-#endif
                 const int t = kWPerProd * pw + i;
                 const int q = k * kWPerGroup + 2 * i + podd;
                 const int b = pgrp * kWRing + q % kWRing;
