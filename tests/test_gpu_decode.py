@@ -190,3 +190,49 @@ def test_per_file_api_is_the_reader_and_k0(tmp_path, capsys):
     random.seed(11)
     m_aug = proc.process_audio_file(p16, augment=True)
     assert m_aug.shape == (80, 32) and np.isfinite(m_aug).all() and not np.array_equal(m_aug, m)
+
+
+def test_two_loaders_over_one_processor_and_seeded_augmented_epochs(tmp_path):
+    """The reference hands ONE AudioProcessor to its train, validation and test datasets (:448-458).  (1) Two loaders over it iterated at
+    the same time (validating in the middle of an epoch, zip(train, val)) each get their own native reader and serve the batches they serve
+    alone; (2) an augmented epoch over files LONGER than 1 s under one `random.seed` repeats bit for bit: the crop draws and the augmentation
+    draws come from python `random` on one thread, in a fixed order (round 3 drew the crops on the reader's helper thread)."""
+    proc = AudioProcessor()
+    pos, neg = [], []
+    for i in range(14):
+        p = os.path.join(tmp_path, f"f{i:02d}.wav")
+        n = 16000 + 700 * i if i % 2 else 16000 - 900 * i                      # half of them need pad_or_truncate's random crop
+        _write_wav(p, np.resize(pkg.synth.make_clip(i), n) * 0.6, 16000)
+        (pos if i < 6 else neg).append(p)
+    train = pkg.WakewordDataset(pos, neg, proc, augment=True, verbose=False)
+    val = pkg.WakewordDataset(pos[0:6:2], neg[0:8:2], proc, verbose=False)                # the files of at most 1 s: no crop draw, no augmentation
+
+    def epoch(ds, seed):
+        random.seed(seed)
+        return [(d.cpu().numpy(), t.cpu().numpy()) for d, t in ds.loader(batch_size=4)]
+    a, b, c = epoch(train, 21), epoch(train, 21), epoch(train, 22)
+    assert len(a) == 4 and all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+    assert any(not np.array_equal(x[0], y[0]) for x, y in zip(a, c))
+    alone = [d.cpu().numpy() for d, _ in val.loader(batch_size=4)]            # deterministic
+    random.seed(5)
+    together = []
+    for (dt, _), (dv, _) in zip(train.loader(batch_size=4), val.loader(batch_size=4)):
+        assert torch.isfinite(dt).all()
+        together.append(dv.cpu().numpy())
+    assert len(together) == 2 and all(np.array_equal(x, y) for x, y in zip(together, alone))
+
+
+def test_load_audio_of_a_long_recording_is_one_upload_and_one_launch(tmp_path):
+    """load_audio (:65-71) returns the whole file; a 12 s recording is twelve 1 s windows of ONE K0 launch (descriptors sharing the bytes),
+    at 16 kHz bit-exact, at 48 kHz against the resampling oracle like the short files."""
+    proc = AudioProcessor()
+    x = np.resize(pkg.synth.make_clip(9) * 0.4, 16000 * 12 + 4321)
+    p = os.path.join(tmp_path, "long16.wav"); _write_wav(p, x, 16000)
+    got = proc.load_audio(p)
+    samples, sr = _read_wav(p)
+    assert got.shape == (len(x),) and np.array_equal(got, decode_oracle.decode(samples, sr))
+    p48 = os.path.join(tmp_path, "long48.wav"); _write_wav(p48, _tone(int(48000 * 7.7), 48000, 3) * 0.7, sr=48000)
+    samples, sr = _read_wav(p48)
+    want = decode_oracle.decode(samples, sr)
+    got = proc.load_audio(p48)
+    assert got.shape == want.shape and len(got) > 7 * 16000 and np.abs(got - want).max() <= 5e-6

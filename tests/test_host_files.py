@@ -120,6 +120,97 @@ def test_reader_reports_the_size_it_needs_and_load_regrows(corpus):
     rd.close()
 
 
+def test_size_fields_that_lie_cost_one_file_not_the_batch(tmp_path):
+    """Round-3 review: sizes written INSIDE a file must not decide how much staging it gets.  A streaming header (RIFF and data size
+    0xFFFFFFFF, what ffmpeg / sox write into a pipe) on a 160 KB file, a header promising 800 k frames on 100 KB of samples and a
+    never-finalised header (data size 0) are each read to the end of the file, like libsndfile does, with the frame count that is really
+    there -- and a batch that holds them fits a staging buffer sized for the bytes on disk (no WW_ENOSPACE, no 4 GB regrow)."""
+    r = np.random.default_rng(11)
+    def s16(n): return r.integers(-30000, 30000, n).astype("<i2").tobytes()
+    def streaming(raw):
+        blob = bytearray(_wav(raw, data_size=0xFFFFFFFF))
+        blob[4:8] = struct.pack("<I", 0xFFFFFFFF)
+        return bytes(blob)
+    cases = {
+        "stream_big.wav": streaming(s16(80000)),                                # 160 KB: beyond the 68 KB head window
+        "stream_small.wav": streaming(s16(3000)),
+        "promises_800k.wav": _wav(s16(50000), data_size=1600000),                # 100 KB of samples
+        "unfinalised.wav": _wav(s16(20001), data_size=0),
+        "unfinalised_big.wav": _wav(s16(70000), data_size=0),
+        "odd_tail.wav": streaming(s16(4000)) + b"\x7f",                         # a trailing half frame is dropped
+        "plain.wav": _wav(s16(16000)),
+    }
+    frames = {"stream_big.wav": 80000, "stream_small.wav": 3000, "promises_800k.wav": 50000, "unfinalised.wav": 20001,
+              "unfinalised_big.wav": 70000, "odd_tail.wav": 4000, "plain.wav": 16000}
+    paths = []
+    for name, blob in cases.items():
+        p = os.path.join(tmp_path, name)
+        with open(p, "wb") as f:
+            f.write(blob)
+        paths.append(p)
+    on_disk = sum((2 * n + 15) // 16 * 16 for n in frames.values())
+    rd = files.WavBatchReader(max_clips=16, max_raw_bytes=on_disk, threads=3, slots=2, host_only=True)
+    descs, status = rd.read(paths, 0)                                            # would raise WW_ENOSPACE if a header's size were believed
+    stage = rd.staging(0)
+    assert len(stage) == on_disk
+    for p, d, st in zip(paths, descs, status):
+        name = os.path.basename(p)
+        assert st == 1 and int(d["n_frames"]) == frames[name], (name, st, int(d["n_frames"]))
+        tag, ch, sr, bits, start, length = _parse_wav(cases[name])
+        off, nbytes = int(d["byte_offset"]), 2 * frames[name]
+        assert bytes(stage[off:off + nbytes]) == cases[name][start:start + nbytes], name
+        info = files.probe(p)
+        assert info["n_frames"] == frames[name] and info["data_offset"] == start, name
+    rd.close()
+
+
+def test_one_reader_serves_one_stream_at_a_time_and_draws_crops_on_the_callers_thread(tmp_path):
+    """Round-3 review: (1) two loaders over ONE processor (the reference hands one AudioProcessor to its train / val / test datasets) shared
+    one reader's slots and thread pool and corrupted each other's batches without a word: a second stream() / load() on a reader whose
+    stream is still alive now raises, and works again once the first is exhausted or closed; (2) pad_or_truncate's crops were drawn with
+    the global `random` on the helper thread, racing the caller's own draws: they are drawn on the caller's thread now, so two seeded
+    passes over files longer than 1 s give the same crops, also with other draws of the caller between the batches."""
+    import random
+    import threading
+    r = np.random.default_rng(3)
+    paths = []
+    for i in range(24):
+        p = os.path.join(tmp_path, f"long{i:02d}.wav")
+        with open(p, "wb") as f:
+            f.write(_wav(r.integers(-30000, 30000, 16000 + 977 * (i + 1)).astype("<i2").tobytes()))
+        paths.append(p)
+    rd = files.WavBatchReader(max_clips=8, max_raw_bytes=1 << 20, threads=2, slots=3, host_only=True)
+    first = rd.stream(paths, 8, verbose=False)
+    next(first)
+    with pytest.raises(RuntimeError, match="still active"):
+        next(rd.stream(paths, 8, verbose=False))
+    with pytest.raises(RuntimeError, match="still active"):
+        rd.load(paths[:4])
+    first.close()
+    assert sum(1 for _ in rd.stream(paths, 8, verbose=False)) == 3           # free again
+
+    def crops(seed):
+        random.seed(seed)
+        out, threads = [], set()
+        orig = files.WavBatchReader.draw_crops
+        def spy(descs, status, n=files.CLIP_SAMPLES):
+            threads.add(threading.get_ident())
+            orig(descs, status, n)
+            out.extend(int(c) for c in descs["crop_start"])
+        files.WavBatchReader.draw_crops = staticmethod(spy)
+        try:
+            for _slot, ok in rd.stream(paths, 8, verbose=False):
+                assert ok.all()
+                random.random(); random.random()                             # the caller's own draws (augmentation plans) between batches
+        finally:
+            files.WavBatchReader.draw_crops = staticmethod(orig)
+        assert threads == {threading.get_ident()}                            # drawn on the consumer's thread
+        return out
+    a, b, c = crops(7), crops(7), crops(8)
+    assert a == b and a != c and len(a) == 24 and all(x >= 0 for x in a) and max(a) > 0
+    rd.close()
+
+
 def test_many_files_many_threads_are_all_accounted_for(tmp_path):
     """512 files of different lengths through 8 threads, three rounds: every payload arrives once, bit for bit."""
     r = np.random.default_rng(1)

@@ -156,6 +156,13 @@ def test_packed_weight_image_layout(arch):
         w = sd[f"conv{li}.weight"].astype(np.float64)
         true_l1 = np.abs(w).reshape(w.shape[0], -1).sum(axis=1).max()
         assert true_l1 <= l1 <= true_l1 * 1.0001 and bm == np.abs(sd[f"conv{li}.bias"]).max()
+    # conv2's Winograd form again as B operands of v_mfma_f32_32x32x16_f16 (cnn2x_kernel): [nt32][xi][step = dx*2 + c][hi/lo][lane][j], lane
+    # (n = lane % 32, hh = lane // 32) holds U_xi[dx][ci = 16 c + 8 hh + j][co = 32 nt + n]; the scales are the 16x16x32 image's (Sw)
+    hx = take(2 * 4 * 6 * 2 * 64 * 4).view(np.float16).astype(np.float64).reshape(2, 4, 3, 2, 2, 64, 8)     # [nt][xi][dx][c][hi/lo][lane][j]
+    nt, xi, dx, c, lane, j = np.meshgrid(np.arange(2), np.arange(4), np.arange(3), np.arange(2), np.arange(64), np.arange(8), indexing="ij")
+    co = 32 * nt + (lane & 31)
+    wantx = U[co, 16 * c + 8 * (lane >> 5) + j, xi, dx] * 2.0 ** Sw[co]
+    assert np.abs((hx[:, :, :, :, 0] + hx[:, :, :, :, 1]) - wantx).max() <= 2.0 ** 13 * 2.0 ** -21
     assert o == p.size
 
 

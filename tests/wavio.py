@@ -18,6 +18,9 @@ def _parse_wav(data: bytes):
                 tag = int.from_bytes(body[24:26], "little")
             fmt = (tag, ch, sr, bits)
         elif cid == b"data":
+            if size in (0, 0xFFFFFFFF):                    # unfinalised / streaming header: to the end of the file (libsndfile's reading)
+                where = (pos + 8, len(data) - pos - 8)
+                break
             where = (pos + 8, min(size, len(data) - pos - 8))
         pos += 8 + size + (size & 1)
     if fmt is None or where is None:
@@ -42,6 +45,9 @@ def _read_wav(path: str):
                 tag = int.from_bytes(body[24:26], "little")
             fmt = (tag, ch, sr, bits)
         elif cid == b"data":
+            if size in (0, 0xFFFFFFFF):
+                pcm = data[pos + 8:]
+                break
             pcm = body
         pos += 8 + size + (size & 1)
     if fmt is None or pcm is None:

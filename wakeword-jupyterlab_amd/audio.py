@@ -42,9 +42,12 @@ class AudioProcessor:
     # ---- reference API --------------------------------------------------------------------------
     def load_audio(self, file_path):
         """= librosa.load(path, sr=16000) (:65-71): the WHOLE file as float32 at 16 kHz mono, or None (prints the error, never raises on a
-        bad file).  Native reader -> K0, one second of output per launch (K0 writes 1 s windows); no normalisation, no crop."""
+        bad file).  Native reader, then ONE upload of the file's bytes and ONE K0 launch over all its 1 s windows (descriptors that share the
+        byte offset and differ in crop_start; without normalisation K0 computes a window's samples only): linear in the file's length
+        (round 3 uploaded and resampled the whole file once per second of it).  No normalisation, no crop."""
+        import ctypes as C
         from . import _native as nat
-        from .files import CLIP_SAMPLES
+        from .files import CLIP_SAMPLES, DESC_DTYPE
         rd = self.gpu_reader(1)                                   # raises without a GPU: a missing device is not a bad file
         try:
             slot = rd.next_slot()
@@ -59,11 +62,19 @@ class AudioProcessor:
             if status[0] != 1:
                 raise ValueError(nat.WAV_STATUS.get(int(status[0]), int(status[0])))
             n_out = int(-(-(int(descs["n_frames"][0]) * int(descs["up"][0])) // max(1, int(descs["down"][0]))))
-            parts = []
-            for start in range(0, n_out, CLIP_SAMPLES):
-                descs["crop_start"][0] = start
-                parts.append(rd.decode(slot, normalize=False)[0].cpu())          # .cpu() synchronises: the descriptor may change again
-            audio = torch.cat(parts)[:n_out].numpy() if parts else np.zeros(0, dtype=np.float32)
+            if n_out == 0:
+                return np.zeros(0, dtype=np.float32)
+            n_win = -(-n_out // CLIP_SAMPLES)
+            win = np.repeat(np.asarray(descs[:1]), n_win)                        # a copy: same bytes, same filter, one window each
+            win["crop_start"] = np.arange(n_win, dtype=np.int64) * CLIP_SAMPLES
+            dev = self._dev()
+            with torch.cuda.device(dev):
+                raw_dev = torch.from_numpy(rd.staging(slot)).to(dev)
+                descs_dev = torch.from_numpy(win.view(np.uint8).reshape(n_win, DESC_DTYPE.itemsize)).to(dev)
+                out = torch.empty((n_win, CLIP_SAMPLES), device=dev, dtype=torch.float32)
+                nat.check(nat.lib.ww_decode_resample(C.c_void_p(raw_dev.data_ptr()), C.c_void_p(descs_dev.data_ptr()), n_win, 0,
+                                                     C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                audio = out.reshape(-1)[:n_out].cpu().numpy()
             return np.ascontiguousarray(audio, dtype=np.float32)
         except Exception as e:                                             # reference: print and return None (:66-71)
             print(f"Error loading {file_path}: {e}")

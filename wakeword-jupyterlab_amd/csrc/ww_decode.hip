@@ -162,7 +162,11 @@ __global__ __launch_bounds__(kRsThreads) void resample_lds_kernel(const uint8_t*
             int64_t i = c < 0 ? -1 : c / up;
             return i > n_in - 1 ? n_in - 1 : i;
         };
-        for (int64_t j0 = 0; j0 < total; j0 += blk) {
+        // without normalisation nothing outside the 1 s window is needed (no whole-file peak): load_audio's windows then cost one window each,
+        // not one file each (round-3 review: a long recording was resampled once per second of its length); per output the same fma chain
+        const int64_t j_begin = normalize ? 0 : d.crop_start;
+        const int64_t j_end = normalize || total < d.crop_start + kClip ? total : d.crop_start + kClip;
+        for (int64_t j0 = j_begin; j0 < j_end; j0 += blk) {
             const int64_t j1 = (j0 + blk < n_out ? j0 + blk : n_out) - 1;       // last filtered output of the block (j1 < j0: none)
             const int64_t i_min = first_in((j0 + n_pre_remove) * int64_t(down) - n_pre_pad);
             const int64_t i_max = j1 >= j0 ? last_in((j1 + n_pre_remove) * int64_t(down) - n_pre_pad) : i_min - 1;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kRsThreads) void resample_lds_kernel(const uint8_t*
             const int crel0 = int((j0 + n_pre_remove) * int64_t(down) - n_pre_pad - i_min * up);
             const int64_t room = n_in - 1 - i_min;
             const int i_cap = room < kRsSpan ? int(room) : kRsSpan;
-            const int jn = int((j0 + blk < total ? j0 + blk : total) - j0);
+            const int jn = int((j0 + blk < j_end ? j0 + blk : j_end) - j0);
             for (int jj = tid; jj < jn; jj += kRsThreads) {
                 const int64_t j = j0 + jj;
                 float y = 0.f;
@@ -274,7 +278,9 @@ __global__ __launch_bounds__(256) void decode_resample_kernel(const uint8_t* __r
         }
 #endif
         const int64_t total = n_out > d.crop_start + kClip ? n_out : d.crop_start + kClip;   // also writes the zero pad
-        for (int64_t j = tid; j < total; j += 256) {
+        const int64_t j_begin = normalize ? 0 : d.crop_start;          // see resample_lds_kernel
+        const int64_t j_end = normalize || total < d.crop_start + kClip ? total : d.crop_start + kClip;
+        for (int64_t j = j_begin + tid; j < j_end; j += 256) {
             float y = 0.f;
             if (j < n_out) {
                 if (up == 1 && down == 1) {

@@ -74,6 +74,9 @@ static int parse_wav(int fd, int64_t fsize, const uint8_t* win, int64_t win_len,
         } else if (!std::memcmp(h, "data", 4)) {
             w->data_start = pos + 8;
             const int64_t rest = fsize - pos - 8;
+            // a size of 0xFFFFFFFF (what ffmpeg / sox write into a pipe) or 0 (a header that was never finalised) means "to the end of
+            // the file", as libsndfile reads it; nothing can follow such a chunk
+            if (size == 0 || size == 0xFFFFFFFFll) { w->data_len = rest; break; }
             w->data_len = size < rest ? size : rest;
         }
         pos += 8 + size + (size & 1);
@@ -83,8 +86,10 @@ static int parse_wav(int fd, int64_t fsize, const uint8_t* win, int64_t win_len,
 }
 
 // The head of the file in ONE read, and the file's size from that read (a short read of a regular file is its end) or, for files larger
-// than the window, from the RIFF header's own size field instead of an fstat; a size field that cannot be right sends the file through
-// fstat.  Whatever of the sample data the window does not hold is read straight into the pinned staging buffer.
+// than the window, from fstat (one more syscall, only for files over 68 KB).  The size fields INSIDE the file are never trusted for how
+// much staging a file gets: a streaming header (RIFF / data size 0xFFFFFFFF) or a truncated file would otherwise reserve gigabytes and
+// fail the whole batch with WW_ENOSPACE (round-3 review); every length is clamped to the bytes that exist.  Whatever of the sample data
+// the window does not hold is read straight into the pinned staging buffer.
 #ifndef WW_HEAD_WINDOW
 #define WW_HEAD_WINDOW 69632
 #endif
@@ -98,13 +103,10 @@ static int64_t read_head(int fd, uint8_t* win, int64_t* fsize_out) {
     const int64_t got = r;
     int64_t fsize = got;                                          // a short read of a regular file is its end
     if (got == kHeadWindow) {
-        const int64_t riff = !std::memcmp(win, "RIFF", 4) ? int64_t(le32(win + 4)) + 8 : 0;
-        if (riff > kHeadWindow) fsize = riff;                     // the logical size; a truncated file shows up as a short sample read
-        else {
-            struct stat sb;
-            if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
-            fsize = int64_t(sb.st_size);
-        }
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
+        fsize = int64_t(sb.st_size);
+        if (fsize < got) fsize = got;                             // the file grew or shrank under us: what was read is there
     }
     *fsize_out = fsize;
     return got;

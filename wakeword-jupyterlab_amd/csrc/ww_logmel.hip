@@ -612,9 +612,12 @@ extern "C" __attribute__((visibility("default"))) int ww_debug_stamps(unsigned l
 // rounding floor ~165 dB under the frame's energy; mel bands of noise-free signals (pure tones, clean speech with digital
 // silence) that lie 60-80 dB under the clip's peak sit on it and come out up to 3.4e-4 dB off.  This kernel is selected
 // by ww_set_logmel_math(WW_LOGMEL_MATH_F64), or per clip by the auto mode (below).
-// Same radix 8 x 8 x 16 structure and the same exchange index maps as the float kernel, with a 16-byte complex as the
-// unit (two ds_read/write_b128 per pair); power spectrum, sparse mel and the dB epilogue are the float kernel's.
-// 4 waves, one 93 KB workgroup per CU.  ONLY_FLAGGED: redo only the clips the float kernel marked (auto mode).
+// Same radix 8 x 8 x 16 structure and the same exchange index maps as the float kernel.  The float kernel's exchange unit is one float4 =
+// (a, b), two complex floats of the lane's two interleaved sub-transforms; here a and b are 16-byte complex doubles and live in TWO PLANES
+// of the slab (a at unit index i, b at 512 + i): every ds_read/write_b128 then sees exactly the float kernel's conflict-free index maps.
+// (Round 3 kept (a, b) side by side as one 32-byte unit: the maps were tuned for 16-byte units, at 32 bytes two lanes of every 16-lane
+// group fell on one bank quad -- 41 % of the kernel's LDS cycles were bank conflicts.)  Power spectrum, sparse mel and the dB epilogue are
+// the float kernel's.  4 waves, 80 KB of LDS: two workgroups per CU.  ONLY_FLAGGED: redo only the clips the float kernel marked (auto mode).
 // ------------------------------------------------------------------------------------------------
 struct cd { double x, y; };
 struct alignas(16) cd2 { cd a, b; };      // two complex doubles = one exchange unit
@@ -663,12 +666,14 @@ constexpr int k64OffPinfo = k64OffRed + 16;
 constexpr int k64OffFp0 = k64OffPinfo + kPieces;
 constexpr int k64OffFcnt = k64OffFp0 + kMels;
 constexpr int k64OffTw2 = (k64OffFcnt + kMels + 3) & ~3;     // [7][16] complex doubles
-constexpr int k64OffTwp = k64OffTw2 + 7 * 16 * 4;           // [512] complex doubles
-constexpr int k64LdsFloats = k64OffTwp + 512 * 4;
+constexpr int k64LdsFloats = k64OffTw2 + 7 * 16 * 4;
 static_assert(k64OffMel % 4 == 0 && k64OffTw2 % 4 == 0, "16-byte alignment of the double tables");
+// Round 4: TWO workgroups per CU (two waves per SIMD; round 3 ran one 93 KB workgroup = one wave per SIMD, every LDS and L2 round trip
+// exposed): the 8 KB pair-twiddle table is read through L1 like the window and the pass-1 twiddles, which brings a workgroup under 80 KB.
+static_assert(sizeof(float) * k64LdsFloats + 512 <= 80 * 1024, "two logmel64 workgroups per CU");
 
 template <bool RING, bool ONLY_FLAGGED>
-__global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restrict__ pcm, int64_t clip_stride, int clip_len, int n_clips,
+__global__ __launch_bounds__(256, 2) void logmel64_kernel(const float* __restrict__ pcm, int64_t clip_stride, int clip_len, int n_clips,
                                                           int normalize, const int32_t* __restrict__ ring_pos_p, int ring_len,
                                                           const LogmelTables* __restrict__ tb, float* __restrict__ out) {
     constexpr int kWavesPerBlock = 4, kThreads = 256;
@@ -679,12 +684,12 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
     const int* fp0 = reinterpret_cast<const int*>(lds + k64OffFp0);
     const int* fcnt = reinterpret_cast<const int*>(lds + k64OffFcnt);
     const cd2* tw2_u = reinterpret_cast<const cd2*>(lds + k64OffTw2);      // [7][8] units = two twiddles each
-    const cd* twp_c = reinterpret_cast<const cd*>(lds + k64OffTwp);
+    const cd* twp_c = reinterpret_cast<const cd*>(&tb->twp_d[0]);          // through L1 (8 KB, every frame)
     const float4* pw4 = reinterpret_cast<const float4*>(&tb->piece_w[0][0][0]);
     const cd2* tw1_u = reinterpret_cast<const cd2*>(&tb->tw1_d[0][0]);     // [7][64] units
     const double* win = &tb->window_d[0];
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane_id = tid & 63, lane = lane_id;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (ONLY_FLAGGED) {
         // auto mode, usually nothing to do: look at the marks of all this workgroup's clips at once and leave before the
@@ -695,8 +700,9 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
         if (!__syncthreads_or(any)) return;
     }
     float* slabf = lds + wave * kSlab64;                        // power spectrum / piece sums (floats) reuse the slab
-    cd2* slabu = reinterpret_cast<cd2*>(slabf);                 // exchange units (the float kernel's float4 indices)
     cd* slabc = reinterpret_cast<cd*>(slabf);                   // single complex values (the float kernel's float2 indices)
+    cd* slabA = slabc;                                          // exchange planes: unit i of the float kernel's float4 map = (slabA[i], slabB[i])
+    cd* slabB = slabc + 512;
     float* partial = slabf + kPartialInSlab;
 
     for (int i = tid; i < kPieces; i += kThreads) reinterpret_cast<int*>(lds)[k64OffPinfo + i] = tb->piece_info[i];
@@ -705,7 +711,6 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
         reinterpret_cast<int*>(lds)[k64OffFcnt + tid] = tb->filt_cnt[tid];
     }
     for (int i = tid; i < 7 * 16 * 2; i += kThreads) reinterpret_cast<double*>(lds + k64OffTw2)[i] = (&tb->tw2_d[0][0].x)[i];
-    for (int i = tid; i < 512 * 2; i += kThreads) reinterpret_cast<double*>(lds + k64OffTwp)[i] = (&tb->twp_d[0].x)[i];
     const int ring_pos = RING ? *ring_pos_p : 0;
     __syncthreads();
     const int my_p0a = fp0[lane], my_cnta = fcnt[lane];
@@ -740,12 +745,17 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
             peak = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
             __syncthreads();
         }
+        // a frame's samples are fetched one frame ahead (in flight under the previous frame's passes 2 and 3)
+        float4 sn[8];
+        load_frame<RING>(sn, rs, wave * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
 #pragma unroll 1
         for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
             const int frame = round * kWavesPerBlock + wave;
+            // opaque copy of the lane id (as in the float kernel): the swizzled LDS addresses below are functions of it, and hoisted out
+            // of the frame loop they cost more VGPRs than the two-waves-per-SIMD budget of 256 has
+            int lane = lane_id;
+            asm volatile("" : "+v"(lane));
             const int k1r = lane >> 3, jr = lane & 7;
-            float4 sn[8];
-            load_frame<RING>(sn, rs, frame * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
             cd za[8], zb[8];
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) {
@@ -758,30 +768,35 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
             // ---- pass 1 ----
             dft8(za);
             dft8(zb);
-            slabu[lane] = {za[0], zb[0]};
+            slabA[lane] = za[0];
+            slabB[lane] = zb[0];
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) {
                 const cd2 t = tw1_u[(k1 - 1) * 64 + lane];
-                slabu[k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)))] = {cmul(za[k1], t.a), cmul(zb[k1], t.b)};
+                const int at = k1 * 64 + (lane ^ (8 * ((k1 >> 1) & 1)));
+                slabA[at] = cmul(za[k1], t.a);
+                slabB[at] = cmul(zb[k1], t.b);
             }
             lds_order();
+            // next frame's samples (the last round fetches past the clip: the descriptor returns zeros, nobody reads them)
+            load_frame<RING>(sn, rs, (frame + kWavesPerBlock) * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
             // ---- pass 2 ----
             {
                 const int s8 = 8 * ((k1r >> 1) & 1);
-                const cd2* x1e = slabu + k1r * 64 + jr + s8;
-                const cd2* x1o = slabu + k1r * 64 + jr - s8;
+                const cd* x1e = slabA + k1r * 64 + jr + s8;
+                const cd* x1o = slabA + k1r * 64 + jr - s8;
 #pragma unroll
                 for (int n2 = 0; n2 < 8; ++n2) {
-                    const cd2 v = (n2 & 1) ? x1o[n2 * 8] : x1e[n2 * 8];
-                    za[n2] = v.a;
-                    zb[n2] = v.b;
+                    const cd* src = (n2 & 1) ? x1o + n2 * 8 : x1e + n2 * 8;
+                    za[n2] = src[0];
+                    zb[n2] = src[512];
                 }
                 lds_order();
                 dft8(za);
                 dft8(zb);
-                cd2* x2w[4];
+                cd* x2w[4];
 #pragma unroll
-                for (int hk = 0; hk < 4; ++hk) x2w[hk] = slabu + 64 * k1r + (jr ^ (4 * (k1r & 1) + hk));
+                for (int hk = 0; hk < 4; ++hk) x2w[hk] = slabA + 64 * k1r + (jr ^ (4 * (k1r & 1) + hk));
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
                     cd a = za[k2], b = zb[k2];
@@ -790,7 +805,8 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
                         a = cmul(a, t.a);
                         b = cmul(b, t.b);
                     }
-                    x2w[k2 >> 1][8 * k2] = {a, b};
+                    x2w[k2 >> 1][8 * k2] = a;
+                    x2w[k2 >> 1][8 * k2 + 512] = b;
                 }
             }
             lds_order();
@@ -800,9 +816,9 @@ __global__ __launch_bounds__(256, 1) void logmel64_kernel(const float* __restric
                 const int sw2 = (lane >> 1) & 7;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
-                    const cd2 v = slabu[lane * 8 + (m ^ sw2)];
-                    u[2 * m] = v.a;
-                    u[2 * m + 1] = v.b;
+                    const cd* src = slabA + lane * 8 + (m ^ sw2);
+                    u[2 * m] = src[0];
+                    u[2 * m + 1] = src[512];
                 }
                 lds_order();
 #ifndef WW_K1_ABL_NODFT16              // timing-only ablation: what pass 3's butterflies cost the vector ALU (results are garbage)
@@ -936,8 +952,8 @@ static int launch_logmel_w(const float* pcm, int64_t n_clips, int64_t clip_strid
 template <bool ONLY_FLAGGED>
 static int launch_logmel64(const float* pcm, int64_t n_clips, int64_t clip_stride, int64_t clip_len, int normalize,
                            const int32_t* ring_pos, int64_t ring_len, float* logmel, const LogmelTables* tb, hipStream_t stream) {
-    const int cus = device_cu_count();
-    const int grid = int(n_clips < cus ? n_clips : cus);
+    const int64_t resident = 2 * int64_t(device_cu_count());      // two 80 KB workgroups per CU
+    const int grid = int(n_clips < resident ? n_clips : resident);
     const size_t lds_bytes = sizeof(float) * k64LdsFloats;
     if (ring_pos)
         hipLaunchKernelGGL((logmel64_kernel<true, ONLY_FLAGGED>), dim3(grid), dim3(256), lds_bytes, stream, pcm, clip_stride, int(clip_len),

@@ -101,6 +101,12 @@ class GpuBatchLoader:
             """(first index, pcm on the device, ok mask) per batch: the native reader one batch ahead (files.WavBatchReader.stream)."""
             from . import _native as nat
             reader = ds.processor.gpu_reader(self.batch_size)
+            if reader._streaming:
+                # the processor's reader is feeding another loader right now (the reference hands ONE processor to its train, validation and
+                # test datasets, :448-458: validating in the middle of an epoch, zip(train, val)): this iteration gets a reader of its own
+                from .files import WavBatchReader
+                reader = WavBatchReader(max_clips=max(64, self.batch_size), max_raw_bytes=max(64, self.batch_size) * 65536, slots=3,
+                                        device=reader.device)
             s = 0
             while s < len(files):
                 try:

@@ -26,9 +26,35 @@ DESC_DTYPE = np.dtype([("byte_offset", "<i8"), ("n_frames", "<i8"), ("channels",
 assert DESC_DTYPE.itemsize == C.sizeof(nat.ClipDesc)
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may use: the smaller of its affinity mask (what `taskset` / a cpuset granted) and its cgroup's CPU quota
+    (cpu.max: a GPU box of this pool shows 256 CPUs in the mask and a quota of 16), divided by the ranks that share the node
+    (LOCAL_WORLD_SIZE, set by torch.distributed.run: one process per GPU)."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                cpus = min(cpus, max(1, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, cpus // ranks)
+
+
 def default_threads() -> int:
-    """Host threads of a reader: the box's CPU share for one GPU is 16; never more than the machine has."""
-    return max(1, min(16, os.cpu_count() or 1))
+    """Host threads of a reader: TWICE this rank's CPU share (host_cpu_share), at most 32 -- a reader thread spends part of its time
+    blocked in open / pread, and on an MI355X box (quota 16 CPUs) 32 threads fed the pipeline 5 % faster than 16 while 64 thrashed
+    against the quota (`profiles/r04_reader_threads.json`) -- or WW_READER_THREADS."""
+    env = os.environ.get("WW_READER_THREADS")
+    if env:
+        return max(1, min(256, int(env)))
+    return max(1, min(32, 2 * host_cpu_share()))
 
 
 class EncodedPaths:
@@ -71,6 +97,7 @@ class WavBatchReader:
         self._n = [0] * self.slots
         self._last_descs = [None] * self.slots
         self._next = 0
+        self._streaming = False        # a stream() generator owns the slots and the thread pool until it is exhausted or closed
 
     def _ctx(self):
         import contextlib
@@ -153,6 +180,7 @@ class WavBatchReader:
     def load(self, paths, normalize: bool = True, out: torch.Tensor | None = None, verbose: bool = True, lo: int = 0, hi: int | None = None):
         """read + crop draw + decode of one batch (`paths[lo:hi]`) on the next slot -> (device tensor [B, 16000], ok mask).
         Unreadable files give a zero row and ok False, with the reference's message (:70)."""
+        self._not_streaming("load")
         hi = len(paths) if hi is None else hi
         n = hi - lo
         if n > self.max_clips:
@@ -174,16 +202,24 @@ class WavBatchReader:
                 print(f"Error loading {names[lo + i]}: {nat.WAV_STATUS.get(int(status[i]), status[i])}")
         return self.decode(slot, normalize, out), ok
 
+    def _not_streaming(self, what: str) -> None:
+        if self._streaming:
+            raise RuntimeError(f"WavBatchReader.{what}: a stream() over this reader is still active (one reader serves one consumer at a time: "
+                               "its slots and thread pool belong to that stream until it is exhausted or closed) -- use a second reader")
+
     def stream(self, paths, batch_size: int, normalize: bool = True, verbose: bool = True, start: int = 0):
         """Generator over `paths` in batches of `batch_size`: yields (device tensor [B, 16000], ok mask) per batch.  A helper thread runs
-        the reader one batch AHEAD (the ctypes call releases the GIL; the crops are drawn there too), the caller's thread only uploads /
-        launches K0 -- the host's file reading then overlaps both the GPU and the caller's own Python work between batches.  Needs a reader
-        with >= 3 slots (one being filled, one waiting, one in flight).  A batch that does not fit the staging buffer raises NativeError
-        (WW_ENOSPACE, `.needed`): size the reader for the largest batch, or `regrow()` it and call stream(..., start=that batch's first index)."""
+        the reader one batch AHEAD (the ctypes call releases the GIL), the caller's thread draws the crops (python `random`, like every other
+        draw of the data path: one thread, so a seeded run repeats -- round 3 drew them on the helper thread, racing the caller's augmentation
+        draws), uploads and launches K0 -- the host's file reading then overlaps both the GPU and the caller's own Python work between
+        batches.  Needs a reader with >= 3 slots (one being filled, one waiting, one in flight).  A batch that does not fit the staging
+        buffer raises NativeError (WW_ENOSPACE, `.needed`): size the reader for the largest batch, or `regrow()` it and call
+        stream(..., start=that batch's first index).  While the generator is alive the reader refuses other load() / stream() calls."""
         import queue
         import threading
         if self.slots < 3:
             raise ValueError("stream() needs a reader with at least 3 slots")
+        self._not_streaming("stream")
         enc = paths if isinstance(paths, EncodedPaths) else EncodedPaths(paths)
         n = len(enc)
         if batch_size < 1 or batch_size > self.max_clips:
@@ -199,13 +235,13 @@ class WavBatchReader:
                     hi = min(n, lo + batch_size)
                     slot = self.next_slot()
                     descs, status = self.read(enc, slot, lo, hi)
-                    self.draw_crops(descs, status)
-                    q.put((slot, lo, status))
+                    q.put((slot, lo, status, descs))
                 q.put(None)
             except BaseException as e:              # noqa: BLE001  (handed to the consumer)
                 q.put(e)
 
         t = threading.Thread(target=producer, name="ww-wav-reader", daemon=True)
+        self._streaming = True
         t.start()
         try:
             while True:
@@ -214,7 +250,8 @@ class WavBatchReader:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                slot, lo, status = item
+                slot, lo, status, descs = item
+                self.draw_crops(descs, status)            # the slot's descriptors stay writable until decode() uploads them
                 ok = status == 1
                 if verbose and not ok.all():
                     for i in np.nonzero(~ok)[0][:8]:
@@ -228,6 +265,7 @@ class WavBatchReader:
                 except queue.Empty:
                     pass
             t.join()
+            self._streaming = False
 
     def regrow(self, max_clips: int, max_raw_bytes: int) -> None:
         """Re-create the reader with larger staging (synchronises the device first: nothing may still read the old buffers)."""
