@@ -338,6 +338,8 @@ def main():
         redone = float((mel_a != mel_f).flatten(1).any(dim=1).float().mean())
         k1_clean = {"workload": f"{B} noise-free 16-bit-quantised signals (tones 110 Hz .. 3.7 kHz, tone pairs, gated tones)",
                     "auto_ms": times["auto"], "f32_ms": times["f32"], "float64_redo_fraction": redone,
+                    # what a digitally clean corpus costs end to end: K1 in auto mode on THIS batch + the timed region's K2 and K3
+                    "e2e_noise_free_clips_per_s": B / ((times["auto"] + k2_ms + k3_ms) * 1e-3),
                     "note": "auto = the float32 kernel + the float64 kernel on the clips it marked; the headline's sine + noise clips mark none"}
         del pcm_c, mel_a, mel_f
 

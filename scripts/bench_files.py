@@ -71,6 +71,7 @@ def measure_decode(batch=4096, steps=10, device=0):
 def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=None, tmp_root=None):
     """WAV files -> logits, end to end, page cache warm (the files were just written)."""
     import wakeword_jupyterlab_amd as pkg
+    from wakeword_jupyterlab_amd import files as files_mod
     from wakeword_jupyterlab_amd.files import EncodedPaths, WavBatchReader, default_threads
     dev = torch.device("cuda", device)
     threads = threads or default_threads()
@@ -126,7 +127,8 @@ def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=
         return {"workload": f"{n_files} WAV files (1 s, 16 kHz, PCM-16, {file_bytes} B each; create_sample_data's format) in a temporary directory, page cache warm "
                             f"-> logits: library reader threads (driven one batch ahead by a helper thread: WavBatchReader.stream) -> pinned staging -> H2D (copy stream) -> K0 -> K1 -> K2 -> K3, batches of {batch}, 3 staging slots, "
                             f"SimpleWakewordModel; {passes} passes over the files",
-                "clips_per_s": n / dt, "ms_per_batch": 1e3 * dt / (n_b * passes), "host_threads": threads, "host_cpus": os.cpu_count(),
+                "clips_per_s": n / dt, "ms_per_batch": 1e3 * dt / (n_b * passes), "host_threads": threads, "host_cpus": os.cpu_count(), "host_cpu_share_of_this_rank": files_mod.host_cpu_share(),
+                "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1),
                 "host_read_only_clips_per_s": n_files / host_dt, "main_thread_ms_waiting_for_reader_per_batch": 1e3 * timing[0] / (n_b * passes),
                 "main_thread_ms_enqueue_per_batch": 1e3 * timing[1] / (n_b * passes),
                 "file_MBps": n * file_bytes / dt / 1e6, "bitwise_repeatable_across_passes": same,

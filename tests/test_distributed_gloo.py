@@ -73,6 +73,46 @@ def test_two_rank_all_gather_of_logits(n_total):
     assert sorted(covered) == list(range(n_total))         # shards partition the batch
 
 
+@pytest.mark.parametrize("n_total", [32768 // 64, 509])
+def test_eight_rank_all_gather_and_pipeline(n_total):
+    """BASELINE configs[3]'s rank count (8 ranks, one per GPU) on CPU: equal shards (512 = 8 x 64) and ragged ones (509: the last rank is
+    short), the padded no-hint form, and the bench step's double-buffered LogitsGatherPipeline at world size 8.  No 8-GPU node was ever
+    available to this build; this is what can be checked without one."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = np.stack([np.arange(n_total, dtype=np.float32), -np.arange(n_total, dtype=np.float32)], 1)
+    covered = []
+    for rank, lo, hi, full, n_nohint in results:
+        assert np.array_equal(full, want)
+        assert n_nohint == world * ((n_total + world - 1) // world)
+        assert hi - lo == (64 if n_total == 512 else (64 if rank < 7 else 509 - 7 * 64))
+        covered += list(range(lo, hi))
+    assert sorted(covered) == list(range(n_total))
+
+
+def test_reader_threads_follow_the_cpu_share_of_a_rank(monkeypatch):
+    """A node's ranks share its CPUs: the file reader's thread count is derived from the affinity mask, the cgroup quota and
+    LOCAL_WORLD_SIZE, not a constant."""
+    from wakeword_jupyterlab_amd import files
+    monkeypatch.delenv("WW_READER_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    one = files.host_cpu_share()
+    assert 1 <= one <= len(os.sched_getaffinity(0))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert files.host_cpu_share() == max(1, one // 8)
+    assert files.default_threads() == max(1, min(32, 2 * max(1, one // 8)))
+    monkeypatch.setenv("WW_READER_THREADS", "5")
+    assert files.default_threads() == 5
+
+
 def test_shard_bounds_partition_any_batch():
     from wakeword_jupyterlab_amd.distributed import shard_bounds
     for n in (0, 1, 5, 4096, 32768, 32769):
