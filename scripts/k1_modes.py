@@ -27,11 +27,17 @@ sig += np.where((idx % 3 == 1)[:, None], 0.25 * np.sin(2 * np.pi * (2.5 * f0)[:,
 sig *= np.where((idx % 5 == 2)[:, None], (tt[None, :] > 0.3), 1.0)
 sig = (np.round(np.clip(sig, -1, 1 - 2.0 ** -15) * 32768.0) / 32768.0).astype(np.float32)
 clean = torch.from_numpy(sig).to(dev)
+# a mixed population: the random noise-free signals of tests/test_gpu_parity.py (about 90 % of the clips marked, ~60 % of their frames)
+_src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "test_gpu_parity.py")).read()
+_ns = {"np": np}
+exec(_src[_src.index("def _random_noise_free_signals"):_src.index("def test_logmel_auto_mode_on_2048_random_noise_free_signals")], _ns)
+rnd = np.concatenate([_ns["_random_noise_free_signals"](2048, 7)[0], _ns["_random_noise_free_signals"](2048, 8)[0]])
+random_clean = torch.from_numpy(rnd).to(dev)
 res = {}
 ref = mel_oracle.logmel_batch(sig[:48], normalize=True)
 for mode in ("f32", "f64", "auto"):
     ops.set_logmel_math(mode)
-    for name, x in (("noisy", noisy), ("clean", clean)):
+    for name, x in (("noisy", noisy), ("clean", clean), ("random_clean", random_clean)):
         for _ in range(3):
             out = ops.logmel(x, True)
         torch.cuda.synchronize()

@@ -152,8 +152,12 @@ __device__ __forceinline__ void load_frame(float4 (&sn)[8], __amdgpu_buffer_rsrc
     }
 }
 
-// NaN with a payload no arithmetic produces: "redo this clip in float64" (written by the float kernel in auto mode into
-// the first word of the clip's output, which the precise kernel then overwrites)
+// NaN with a payload no arithmetic produces: "finish this clip in float64".  Auto mode, round 4: the float kernel's floor test is
+// evaluated per FRAME, and the redo is per frame too: for a marked clip the float kernel leaves
+//     o[0] = kRedoMark,  o[1] = the frames to redo as a bit mask (bits 0 and 1 always set: those two words sit in frames 0 and 1 of band 0),
+//     o[band * 32 + frame] = the mel POWER (after the peak gain, before amin / log) everywhere else,
+// and logmel64_kernel<.., true> recomputes only the masked frames in float64, takes the other frames' powers as they are and does the
+// clip's dB epilogue (round 3 redid all 32 frames of a marked clip).
 constexpr uint32_t kRedoMark = 0x7fc5a11eu;
 // Auto mode's test.  The float FFT leaves rounding noise of about 2.4 eps^2 E / 1024 per bin under a frame of energy
 // E = sum_k |X_k|^2; a band's power P_b = sum_k M_bk |X_k|^2 then carries a relative error of ~2 sigma sqrt(wmax_b / P_b),
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
         reinterpret_cast<int*>(lds)[kOffFcnt + tid] = tb->filt_cnt[tid];
         lds[kOffInvw + tid] = tb->band_bins[tid];                        // 1 / wmax_b
     }
-    if (tid < 4) reinterpret_cast<uint32_t*>(lds)[kOffFlag + tid] = 0u;
+    if (tid < 4) reinterpret_cast<uint32_t*>(lds)[kOffFlag + tid] = 0u;      // [2] frame masks (auto mode), by clip parity
     for (int i = tid; i < 7 * 16 * 2; i += kThreads) lds[kOffTw2 + i] = (&tb->tw2[0][0].x)[i];
     for (int i = tid; i < 512 * 2; i += kThreads) lds[kOffTwp + i] = (&tb->twp[0].x)[i];
     const int ring_pos = RING ? *ring_pos_p : 0;
@@ -258,8 +262,9 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1) t1res[k1 - 1] = tw1_4[(k1 - 1) * 64 + lane_id];
 #endif
+    int clip_it = 0;
 #pragma unroll 1
-    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x, ++clip_it) {
         const __amdgpu_buffer_rsrc_t rs_cur = clip_rsrc(clip), rs_next = clip_rsrc(clip + int(gridDim.x));
         float peak = 0.f;
         // `sn` was prefetched: by the prologue for the first clip, by the previous clip's last frame otherwise
@@ -526,6 +531,10 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
 #endif
         __syncthreads();   // all 32 frames' mel bands are in LDS
         STAMP(6);
+        // auto mode's frame mask lives in flag[clip_it & 1]; the other word (the previous clip's, whose readers are all past the barrier
+        // above) is cleared here for the next clip
+        uint32_t* flag = reinterpret_cast<uint32_t*>(lds) + kOffFlag;
+        if (mark && tid == 0) flag[(clip_it + 1) & 1] = 0u;
 
         // ---- per-clip peak and mel max ----
         // auto mode rides on this pass: every idx of a thread belongs to frame tid & 31, so the thread also sums its share of
@@ -582,12 +591,24 @@ __global__ __launch_bounds__(WAVES * 64, K1Layout<WAVES>::kWavesPerSimd) void lo
             o[idx] = db;
             if (mark) redo |= p > live_thr && p * invw[idx >> 5] < floor_e;     // false for NaN
         }
-        uint32_t* flag = reinterpret_cast<uint32_t*>(lds) + kOffFlag;
-        if (mark && __builtin_amdgcn_ballot_w64(redo) != 0ull && lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __syncthreads();   // mel / red / frm are rewritten by the next clip; the redo flag is complete
-        if (mark && tid == 0 && *flag) {                                    // after this thread's own store of o[0]
-            *flag = 0u;                                                     // the next clip's flag stores come behind its own barriers
-            reinterpret_cast<uint32_t*>(o)[0] = kRedoMark;
+        if (mark) {
+            // every idx of a thread belongs to frame tid & 31 = lane & 31: lanes l and l + 32 of a wave vote for the same frame
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(redo);
+            const uint32_t fm = uint32_t(bal) | uint32_t(bal >> 32);
+            if (fm != 0u && lane == 0) __hip_atomic_fetch_or(flag + (clip_it & 1), fm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();   // the frame mask is complete (mel / red / frm are rewritten only behind the next clip's barriers)
+        if (mark) {
+            const uint32_t fm = flag[clip_it & 1];                           // uniform
+            if (fm != 0u) {
+                // a marked clip: powers instead of dB (the float64 kernel finishes it); words 0 and 1 carry the mark and the mask
+                for (int idx = tid; idx < kMels * kFrames; idx += kThreads)
+                    if (idx >= 2) o[idx] = mel[(idx >> 5) * kMelStride + (idx & 31)] * g2;
+                if (tid == 0) {
+                    reinterpret_cast<uint32_t*>(o)[0] = kRedoMark;
+                    reinterpret_cast<uint32_t*>(o)[1] = fm | 3u;
+                }
+            }
         }
         STAMP(7);
     }
@@ -720,9 +741,23 @@ __global__ __launch_bounds__(256, 2) void logmel64_kernel(const float* __restric
 #pragma unroll 1
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
         float* __restrict__ o = out + int64_t(clip) * (kMels * kFrames);
+        uint32_t fmask = 0xffffffffu;                  // the frames this launch computes; all of them unless the float kernel said which
         if constexpr (ONLY_FLAGGED) {
             if (__builtin_amdgcn_readfirstlane(__float_as_uint(__builtin_nontemporal_load(o))) != kRedoMark) continue;   // uniform
+            fmask = __builtin_amdgcn_readfirstlane(__float_as_uint(__builtin_nontemporal_load(o + 1)));
+#ifdef WW_ABL_WHOLE_CLIP          // A/B: redo every frame of a marked clip (round 3's behaviour)
+            fmask = 0xffffffffu;
+#endif
+            // the other frames' mel powers as the float kernel left them (already carrying the peak gain)
+            for (int idx = tid; idx < kMels * kFrames; idx += kThreads)
+                if (!((fmask >> (idx & 31)) & 1u)) mel[(idx >> 5) * kMelStride + (idx & 31)] = __builtin_nontemporal_load(o + idx);
         }
+        const int n_mine = (__builtin_popcount(fmask) - wave + kWavesPerBlock - 1) / kWavesPerBlock;     // this wave takes the masked frames number wave, wave + 4, ...
+        auto nth_frame = [&](int n) -> int {           // index of the n-th set bit of fmask (scalar); past the last one: a frame outside the clip (zero loads)
+            uint32_t m = fmask;
+            for (int i = 0; i < n && m; ++i) m &= m - 1u;
+            return m ? __builtin_ctz(m) : 64;
+        };
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pcm + int64_t(clip) * clip_stride), 0,
                                                                              clip_bytes, 0x00020000);
         // The reference normalises BEFORE the transform, in float32 (audio / np.max(np.abs(audio)), :73-76): every sample is
@@ -747,10 +782,11 @@ __global__ __launch_bounds__(256, 2) void logmel64_kernel(const float* __restric
         }
         // a frame's samples are fetched one frame ahead (in flight under the previous frame's passes 2 and 3)
         float4 sn[8];
-        load_frame<RING>(sn, rs, wave * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
+        int frame = nth_frame(wave);
+        load_frame<RING>(sn, rs, frame * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
 #pragma unroll 1
-        for (int round = 0; round < kFrames / kWavesPerBlock; ++round) {
-            const int frame = round * kWavesPerBlock + wave;
+        for (int round = 0; round < n_mine; ++round) {
+            const int frame_next = nth_frame((round + 1) * kWavesPerBlock + wave);
             // opaque copy of the lane id (as in the float kernel): the swizzled LDS addresses below are functions of it, and hoisted out
             // of the frame loop they cost more VGPRs than the two-waves-per-SIMD budget of 256 has
             int lane = lane_id;
@@ -779,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void logmel64_kernel(const float* __restric
             }
             lds_order();
             // next frame's samples (the last round fetches past the clip: the descriptor returns zeros, nobody reads them)
-            load_frame<RING>(sn, rs, (frame + kWavesPerBlock) * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
+            load_frame<RING>(sn, rs, frame_next * kHop - kNfft / 2 + 4 * lane, ring_pos, ring_len);
             // ---- pass 2 ----
             {
                 const int s8 = 8 * ((k1r >> 1) & 1);
@@ -825,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void logmel64_kernel(const float* __restric
                 dft16(u);
 #endif
                 const int lp = (lane >> 3) + 8 * (lane & 7);
-                cd* zw = slabc + (lp ^ (((lp >> 4) & 3) << 1));
+                cd* zw = slabc + (lp ^ ((lp >> 3) & 7));      // Z[k] at k ^ ((k >> 3) & 7): 16-byte elements, conflict-free stores and `a` reads
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) zw[64 * kk] = u[kk];
             }
@@ -834,8 +870,8 @@ __global__ __launch_bounds__(256, 2) void logmel64_kernel(const float* __restric
             {
                 cd a[8], b[8];
                 const int lowb = (64 - lane) & 63;
-                const cd* za_p = slabc + (lane ^ (((lane >> 4) & 3) << 1));
-                const cd* zb_p = slabc + (lowb ^ (((lowb >> 4) & 3) << 1)) + (lane == 0 ? 64 : 0);
+                const cd* za_p = slabc + (lane ^ ((lane >> 3) & 7));
+                const cd* zb_p = slabc + (lowb ^ ((lowb >> 3) & 7)) + (lane == 0 ? 64 : 0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     a[j] = za_p[64 * j];
@@ -899,6 +935,7 @@ __global__ __launch_bounds__(256, 2) void logmel64_kernel(const float* __restric
                 }
             }
             lds_order();
+            frame = frame_next;
         }
         __syncthreads();
         // a NaN anywhere (silent clip, 0/0) must reach every output like in the reference: fmaxf would drop it
