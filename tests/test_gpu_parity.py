@@ -371,6 +371,31 @@ def test_custom_ops_are_registered(ops, dev):
     assert out.shape == (2, 1, 80, 32)
 
 
+def test_compiled_ops_agree_with_the_raw_launches_and_trace_under_torch_compile(ops, dev):
+    """The compiled operators (csrc/ww_torch_ops.cpp) against the ctypes launches they replaced, bit for bit, including the inputs that
+    need a copy (strided / unaligned PCM, ragged widths); then a function that calls them traced by torch.compile (backend aot_eager: the
+    graph is captured with FakeTensors -- the Meta kernels -- and run through the real kernels; no code generation involved)."""
+    sd = pkg.synth.make_state_dict("simple", seed=1234)
+    packed = torch.from_numpy(ops.pack_state_dict(sd)).to(dev)
+    pcm = torch.from_numpy(pkg.synth.make_clips(20, 9)).to(dev)
+    wide = torch.zeros(9, 16004, device=dev); wide[:, 3:16003] = pcm[:, :16000]
+    for x in (pcm, pcm[:, :15999], wide[:, 3:16003], pcm[::2], pcm[1:2, :777]):
+        assert torch.equal(torch.ops.wakeword_amd.logmel(x, True), ops._logmel_impl(x, True))
+        assert torch.equal(torch.ops.wakeword_amd.forward_pcm(x, packed, 2, True), ops._forward_pcm_impl(x, packed, 2, True))
+    mel = ops.logmel(pcm, True)
+    for w in (32, 31, 5):
+        m = mel[..., :w]
+        assert torch.equal(torch.ops.wakeword_amd.cnn_pool(m, packed, 2), ops._cnn_pool_impl(m, packed, 2))
+        assert torch.equal(torch.ops.wakeword_amd.cnn_lstm_forward(m, packed, 2), ops._cnn_lstm_forward_impl(m, packed, 2))
+    pooled = ops.cnn_pool(mel, packed, 2)
+    assert torch.equal(torch.ops.wakeword_amd.lstm_fc(pooled, packed, 2), ops._lstm_fc_impl(pooled, packed, 2))
+
+    def path(p):
+        return torch.softmax(torch.ops.wakeword_amd.forward_pcm(p, packed, 2, True), dim=1)[:, 1]
+    traced = torch.compile(path, backend="aot_eager", fullgraph=True)
+    assert torch.equal(traced(pcm), path(pcm))
+
+
 @pytest.mark.parametrize("arch,n,launches", [("full", 777, 1500), ("simple", 1000, 3000)])
 def test_conv_stack_is_bitwise_repeatable_back_to_back(ops, dev, arch, n, launches):
     """Soak: the producer / consumer hand-off inside the conv kernel is counter-synchronised (no workgroup barrier); a hole in

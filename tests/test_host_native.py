@@ -268,3 +268,34 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     env["LD_LIBRARY_PATH"] = os.path.dirname(torch.__file__) + "/lib:" + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([exe, "gpu" if HAS_GPU else "cpu", os.path.join(tmp_path, "abi_check.wav")], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0 and "abi_host_check OK" in r.stdout, r.stderr
+
+
+def test_custom_ops_are_compiled_operators_with_meta_kernels():
+    """torch.ops.wakeword_amd.* come from libwakeword_amd_torch.so (TORCH_LIBRARY + CUDA / Meta / CPU kernels),
+    not from Python registrations: the schemas are there, meta tensors and FakeTensors (what torch.compile / export trace with) get their
+    output shapes without touching a device, CPU tensors are refused."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from wakeword_jupyterlab_amd import ops
+    assert os.path.exists(ops.TORCH_LIB_PATH)
+    loaded = open("/proc/self/maps").read()
+    assert "libwakeword_amd_torch.so" in loaded and "libwakeword_amd.so" in loaded
+    ns = torch.ops.wakeword_amd
+    assert str(ns.logmel.default._schema) == "wakeword_amd::logmel(Tensor pcm, bool normalize=True) -> Tensor"
+    assert str(ns.forward_pcm.default._schema) == "wakeword_amd::forward_pcm(Tensor pcm, Tensor packed, int n_conv, bool normalize=True) -> Tensor"
+    m = lambda *s: torch.empty(*s, device="meta")                               # noqa: E731
+    assert ns.logmel(m(4, 16000), True).shape == (4, 1, 80, 32) and ns.logmel(m(0, 777)).shape == (0, 1, 80, 32)
+    assert ns.cnn_pool(m(3, 1, 80, 31), m(9), 2).shape == (3, 64) and ns.cnn_pool(m(3, 1, 80, 32), m(9), 3).shape == (3, 128)
+    assert ns.lstm_fc(m(5, 128), m(9), 3).shape == (5, 2)
+    assert ns.cnn_lstm_forward(m(6, 1, 80, 32), m(9), 2).shape == (6, 2)
+    assert ns.forward_pcm(m(7, 9000), m(9), 3, False).shape == (7, 2)
+    for bad in (lambda: ns.logmel(m(4, 16001)), lambda: ns.cnn_pool(m(3, 1, 80, 33), m(9), 2), lambda: ns.lstm_fc(m(5, 64), m(9), 3),
+                lambda: ns.forward_pcm(m(7, 9000), m(9), 4)):
+        with pytest.raises(RuntimeError):
+            bad()
+    with FakeTensorMode():                                                       # fake CUDA tensors on a machine without a GPU
+        y = ns.cnn_lstm_forward(torch.empty(5, 1, 80, 32, device="cuda"), torch.empty(100, device="cuda"), 2)
+        z = ops.logmel(torch.empty(2, 16000, device="cuda"), True)               # the Python wrapper's checks run on fake tensors too
+        assert y.shape == (5, 2) and y.device.type == "cuda" and z.shape == (2, 1, 80, 32)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        ns.lstm_fc(torch.zeros(2, 64), torch.zeros(4), 2)

@@ -141,7 +141,10 @@ def _load():
             f"{LIB_PATH} is missing: the HIP library is the only implementation of this path (no CPU "
             "fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C wakeword-jupyterlab_amd/csrc`.")
-    lib = C.CDLL(LIB_PATH)
+    # RTLD_GLOBAL: libwakeword_amd_torch.so (the compiled torch.ops.wakeword_amd.* operators, ops.py) is built without linking this library
+    # and binds its ww_* calls to whichever copy is loaded here -- the shipped one, or an ablation / diagnostic build (WW_LIB_OVERRIDE).
+    # Only the C ABI is exported (-fvisibility=hidden), so nothing else enters the global scope.
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args

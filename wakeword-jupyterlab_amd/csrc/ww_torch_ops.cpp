@@ -1,0 +1,199 @@
+// torch.ops.wakeword_amd.* as COMPILED operators: schema, CUDA (= HIP on ROCm) kernels over the C ABI, Meta (shape-only) kernels, and a
+// CPU kernel that refuses -- SURVEY.md section 7 step 2 / section 8 boundary B1-B3.  Rounds 1-3 registered Python functions through
+// torch.library (no Meta kernel: FakeTensor tracing / torch.compile of the drop-in modules could not work, and every call paid Python
+// dispatch); this translation unit replaces them.  It is host code only: it validates tensors, allocates outputs with ATen and calls
+//   ww_logmel_f32 / ww_cnn_pool_f32 / ww_lstm_fc_f32 / ww_model_forward_f32 / ww_forward_pcm_f32      (include/wakeword_amd.h)
+// on torch's current HIP stream.  The ww_* symbols are NOT linked at build time: the Python package loads libwakeword_amd.so (or the
+// build named by WW_LIB_OVERRIDE) with RTLD_GLOBAL first and this library binds to whichever copy that was.
+//
+// Reference call sites these operators stand behind: AudioProcessor.audio_to_mel (wakeword_training_script.py:85-101) -> logmel;
+// SimpleWakewordModel.forward (wakeword_training/train_wakeword.py:38-49) / WakewordModel.forward (wakeword_training_script.py:167-184)
+// -> cnn_lstm_forward (= cnn_pool + lstm_fc); the batched inference loop (notebook cell 17) on raw clips -> forward_pcm.
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "wakeword_amd.h"
+
+namespace {
+
+constexpr int64_t kClip = WW_CLIP_SAMPLES, kMels = WW_N_MELS, kFrames = WW_N_FRAMES;
+
+void* stream_of(const at::Tensor& t) { return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream()); }
+
+void check_rc(int64_t rc, const char* what) {
+    TORCH_CHECK(rc >= 0, "wakeword_amd::", what, ": ", ww_last_error() ? ww_last_error() : "native call failed", " (code ", rc, ")");
+}
+
+void require_cuda_f32(const at::Tensor& t, const char* name) {
+    TORCH_CHECK(t.device().is_cuda(), name, " is on ", t.device(), ": this path has no CPU implementation; move it to the MI355X (`.cuda()`)");
+    TORCH_CHECK(t.scalar_type() == at::kFloat, name, ": expected float32, got ", t.scalar_type());
+}
+
+int64_t c_last(int64_t n_conv) {
+    TORCH_CHECK(n_conv == 2 || n_conv == 3, "n_conv must be 2 or 3, got ", n_conv);
+    return n_conv == 2 ? 64 : 128;
+}
+
+// [B, n <= 16000] float32 with unit sample stride, row stride a multiple of 4 floats and a 16-byte aligned base, copying only if needed
+at::Tensor checked_pcm(const at::Tensor& pcm) {
+    require_cuda_f32(pcm, "pcm");
+    TORCH_CHECK(pcm.dim() == 2, "pcm: expected [B, samples], got ", pcm.sizes());
+    const int64_t B = pcm.size(0), n = pcm.size(1);
+    TORCH_CHECK(n >= 1 && n <= kClip, "pcm: ", n, " samples per clip; the front-end takes 1..", kClip,
+                " (crop longer clips on the host, pad_or_truncate wakeword_training_script.py:78-83)");
+    if (pcm.stride(1) == 1 && (B <= 1 || pcm.stride(0) % 4 == 0) && reinterpret_cast<uintptr_t>(pcm.data_ptr()) % 16 == 0) return pcm;
+    at::Tensor p = pcm.contiguous();
+    if (n % 4 && B > 1) {
+        at::Tensor pad = at::zeros({B, (n + 3) / 4 * 4}, pcm.options());
+        pad.narrow(1, 0, n).copy_(p);
+        p = pad.narrow(1, 0, n);
+    }
+    return p;
+}
+
+at::Tensor checked_x(const at::Tensor& x) {
+    require_cuda_f32(x, "x");
+    TORCH_CHECK(x.dim() == 4 && x.size(1) == 1 && x.size(2) == kMels, "x: expected [B, 1, ", kMels, ", T], got ", x.sizes());
+    TORCH_CHECK_NOT_IMPLEMENTED(x.size(3) >= 1 && x.size(3) <= 32, "x: T = ", x.size(3), " frames; the conv kernels are built for 1..32 (1 s clips give 32)");
+    return x.contiguous();
+}
+
+void check_packed(const at::Tensor& packed, int64_t n_conv, const at::Tensor& like) {
+    require_cuda_f32(packed, "packed weights");
+    TORCH_CHECK(packed.device() == like.device(), "packed weights on ", packed.device(), ", input on ", like.device());
+    TORCH_CHECK((n_conv == 2 || n_conv == 3) && packed.is_contiguous() && packed.numel() == ww_packed_weights_floats(int32_t(n_conv)),
+                "packed weights do not match n_conv (use ops.pack_state_dict)");
+}
+
+// ---------------------------------------------------------------- CUDA (HIP) kernels
+at::Tensor logmel_cuda(const at::Tensor& pcm_in, bool normalize) {
+    const at::Tensor pcm = checked_pcm(pcm_in);
+    const int64_t B = pcm.size(0), n = pcm.size(1);
+    at::Tensor out = at::empty({B, 1, kMels, kFrames}, pcm.options());
+    c10::DeviceGuard guard(pcm.device());
+    check_rc(ww_logmel_f32(pcm.data_ptr<float>(), B, B > 1 ? pcm.stride(0) : n, n, normalize ? 1 : 0, out.data_ptr<float>(), stream_of(pcm)), "logmel");
+    return out;
+}
+
+at::Tensor cnn_pool_cuda(const at::Tensor& x_in, const at::Tensor& packed, int64_t n_conv) {
+    const at::Tensor x = checked_x(x_in);
+    check_packed(packed, n_conv, x);
+    const int64_t B = x.size(0), T = x.size(3);
+    at::Tensor pooled = at::empty({B, c_last(n_conv)}, x.options());
+    const int64_t nbytes = ww_cnn_scratch_bytes(B, int32_t(n_conv));
+    check_rc(nbytes, "cnn_pool");
+    at::Tensor scratch = at::empty({nbytes > 0 ? nbytes : 1}, x.options().dtype(at::kByte));
+    c10::DeviceGuard guard(x.device());
+    check_rc(ww_cnn_pool_f32(x.data_ptr<float>(), B, int32_t(T), packed.data_ptr<float>(), int32_t(n_conv), nbytes > 0 ? scratch.data_ptr() : nullptr,
+                             pooled.data_ptr<float>(), stream_of(x)), "cnn_pool");
+    return pooled;
+}
+
+at::Tensor lstm_fc_cuda(const at::Tensor& pooled_in, const at::Tensor& packed, int64_t n_conv) {
+    require_cuda_f32(pooled_in, "pooled");
+    check_packed(packed, n_conv, pooled_in);
+    TORCH_CHECK(pooled_in.dim() == 2 && pooled_in.size(1) == c_last(n_conv), "pooled: expected [B, ", c_last(n_conv), "], got ", pooled_in.sizes());
+    const at::Tensor pooled = pooled_in.contiguous();
+    at::Tensor logits = at::empty({pooled.size(0), 2}, pooled.options());
+    c10::DeviceGuard guard(pooled.device());
+    check_rc(ww_lstm_fc_f32(pooled.data_ptr<float>(), pooled.size(0), packed.data_ptr<float>(), int32_t(n_conv), logits.data_ptr<float>(),
+                            stream_of(pooled)), "lstm_fc");
+    return logits;
+}
+
+at::Tensor workspace(int64_t n, int64_t n_conv, const at::Tensor& like) {
+    const int64_t nbytes = ww_workspace_bytes(n, int32_t(n_conv));
+    check_rc(nbytes, "workspace");
+    return at::empty({nbytes > 0 ? nbytes : 1}, like.options().dtype(at::kByte));
+}
+
+at::Tensor cnn_lstm_forward_cuda(const at::Tensor& x_in, const at::Tensor& packed, int64_t n_conv) {
+    const at::Tensor x = checked_x(x_in);
+    check_packed(packed, n_conv, x);
+    const int64_t B = x.size(0), T = x.size(3);
+    at::Tensor logits = at::empty({B, 2}, x.options());
+    at::Tensor ws = workspace(B, n_conv, x);
+    c10::DeviceGuard guard(x.device());
+    check_rc(ww_model_forward_f32(x.data_ptr<float>(), B, int32_t(T), packed.data_ptr<float>(), int32_t(n_conv), ws.data_ptr(), logits.data_ptr<float>(),
+                                  stream_of(x)), "cnn_lstm_forward");
+    return logits;
+}
+
+at::Tensor forward_pcm_cuda(const at::Tensor& pcm_in, const at::Tensor& packed, int64_t n_conv, bool normalize) {
+    const at::Tensor pcm = checked_pcm(pcm_in);
+    check_packed(packed, n_conv, pcm);
+    const int64_t B = pcm.size(0), n = pcm.size(1);
+    at::Tensor logits = at::empty({B, 2}, pcm.options());
+    at::Tensor ws = workspace(B, n_conv, pcm);
+    c10::DeviceGuard guard(pcm.device());
+    check_rc(ww_forward_pcm_f32(pcm.data_ptr<float>(), B, B > 1 ? pcm.stride(0) : n, n, normalize ? 1 : 0, packed.data_ptr<float>(), int32_t(n_conv),
+                                ws.data_ptr(), logits.data_ptr<float>(), stream_of(pcm)), "forward_pcm");
+    return logits;
+}
+
+// ---------------------------------------------------------------- Meta kernels: shapes only (FakeTensor / torch.compile tracing)
+at::Tensor logmel_meta(const at::Tensor& pcm, bool) {
+    TORCH_CHECK(pcm.dim() == 2 && pcm.size(1) >= 1 && pcm.size(1) <= kClip, "pcm: expected [B, 1..", kClip, "], got ", pcm.sizes());
+    return at::empty({pcm.size(0), 1, kMels, kFrames}, pcm.options().dtype(at::kFloat));
+}
+at::Tensor cnn_pool_meta(const at::Tensor& x, const at::Tensor&, int64_t n_conv) {
+    TORCH_CHECK(x.dim() == 4 && x.size(1) == 1 && x.size(2) == kMels && x.size(3) >= 1 && x.size(3) <= 32, "x: expected [B, 1, ", kMels, ", 1..32], got ", x.sizes());
+    return at::empty({x.size(0), c_last(n_conv)}, x.options().dtype(at::kFloat));
+}
+at::Tensor lstm_fc_meta(const at::Tensor& pooled, const at::Tensor&, int64_t n_conv) {
+    TORCH_CHECK(pooled.dim() == 2 && pooled.size(1) == c_last(n_conv), "pooled: expected [B, ", c_last(n_conv), "], got ", pooled.sizes());
+    return at::empty({pooled.size(0), 2}, pooled.options().dtype(at::kFloat));
+}
+at::Tensor cnn_lstm_forward_meta(const at::Tensor& x, const at::Tensor&, int64_t n_conv) {
+    TORCH_CHECK(x.dim() == 4 && x.size(1) == 1 && x.size(2) == kMels && x.size(3) >= 1 && x.size(3) <= 32, "x: expected [B, 1, ", kMels, ", 1..32], got ", x.sizes());
+    (void)c_last(n_conv);
+    return at::empty({x.size(0), 2}, x.options().dtype(at::kFloat));
+}
+at::Tensor forward_pcm_meta(const at::Tensor& pcm, const at::Tensor&, int64_t n_conv, bool) {
+    TORCH_CHECK(pcm.dim() == 2 && pcm.size(1) >= 1 && pcm.size(1) <= kClip, "pcm: expected [B, 1..", kClip, "], got ", pcm.sizes());
+    (void)c_last(n_conv);
+    return at::empty({pcm.size(0), 2}, pcm.options().dtype(at::kFloat));
+}
+
+// ---------------------------------------------------------------- CPU: there is none
+[[noreturn]] void no_cpu(const char* name) {
+    TORCH_CHECK(false, "wakeword_amd::", name, ": no CPU implementation exists (HIP/gfx950 only); move the tensors to the GPU");
+}
+at::Tensor logmel_cpu(const at::Tensor&, bool) { no_cpu("logmel"); }
+at::Tensor cnn_pool_cpu(const at::Tensor&, const at::Tensor&, int64_t) { no_cpu("cnn_pool"); }
+at::Tensor lstm_fc_cpu(const at::Tensor&, const at::Tensor&, int64_t) { no_cpu("lstm_fc"); }
+at::Tensor cnn_lstm_forward_cpu(const at::Tensor&, const at::Tensor&, int64_t) { no_cpu("cnn_lstm_forward"); }
+at::Tensor forward_pcm_cpu(const at::Tensor&, const at::Tensor&, int64_t, bool) { no_cpu("forward_pcm"); }
+
+}  // namespace
+
+TORCH_LIBRARY(wakeword_amd, m) {
+    m.def("logmel(Tensor pcm, bool normalize=True) -> Tensor");
+    m.def("cnn_pool(Tensor x, Tensor packed, int n_conv) -> Tensor");
+    m.def("lstm_fc(Tensor pooled, Tensor packed, int n_conv) -> Tensor");
+    m.def("cnn_lstm_forward(Tensor x, Tensor packed, int n_conv) -> Tensor");
+    m.def("forward_pcm(Tensor pcm, Tensor packed, int n_conv, bool normalize=True) -> Tensor");
+}
+TORCH_LIBRARY_IMPL(wakeword_amd, CUDA, m) {
+    m.impl("logmel", &logmel_cuda);
+    m.impl("cnn_pool", &cnn_pool_cuda);
+    m.impl("lstm_fc", &lstm_fc_cuda);
+    m.impl("cnn_lstm_forward", &cnn_lstm_forward_cuda);
+    m.impl("forward_pcm", &forward_pcm_cuda);
+}
+TORCH_LIBRARY_IMPL(wakeword_amd, Meta, m) {
+    m.impl("logmel", &logmel_meta);
+    m.impl("cnn_pool", &cnn_pool_meta);
+    m.impl("lstm_fc", &lstm_fc_meta);
+    m.impl("cnn_lstm_forward", &cnn_lstm_forward_meta);
+    m.impl("forward_pcm", &forward_pcm_meta);
+}
+TORCH_LIBRARY_IMPL(wakeword_amd, CPU, m) {
+    m.impl("logmel", &logmel_cpu);
+    m.impl("cnn_pool", &cnn_pool_cpu);
+    m.impl("lstm_fc", &lstm_fc_cpu);
+    m.impl("cnn_lstm_forward", &cnn_lstm_forward_cpu);
+    m.impl("forward_pcm", &forward_pcm_cpu);
+}

@@ -190,47 +190,69 @@ def _forward_pcm_impl(pcm: torch.Tensor, packed: torch.Tensor, n_conv: int, norm
 # ------------------------------------------------------------------------------------------------
 # torch custom ops: torch.ops.wakeword_amd.{logmel,cnn_pool,lstm_fc,cnn_lstm_forward,forward_pcm}
 # ------------------------------------------------------------------------------------------------
-_lib = torch.library.Library("wakeword_amd", "DEF")
-_lib.define("logmel(Tensor pcm, bool normalize=True) -> Tensor")
-_lib.define("cnn_pool(Tensor x, Tensor packed, int n_conv) -> Tensor")
-_lib.define("lstm_fc(Tensor pooled, Tensor packed, int n_conv) -> Tensor")
-_lib.define("cnn_lstm_forward(Tensor x, Tensor packed, int n_conv) -> Tensor")
-_lib.define("forward_pcm(Tensor pcm, Tensor packed, int n_conv, bool normalize=True) -> Tensor")
-_lib.impl("logmel", _logmel_impl, "CUDA")
-_lib.impl("cnn_pool", _cnn_pool_impl, "CUDA")
-_lib.impl("lstm_fc", _lstm_fc_impl, "CUDA")
-_lib.impl("cnn_lstm_forward", _cnn_lstm_forward_impl, "CUDA")
-_lib.impl("forward_pcm", _forward_pcm_impl, "CUDA")
+# COMPILED operators (csrc/ww_torch_ops.cpp -> libwakeword_amd_torch.so: TORCH_LIBRARY schema + CUDA, Meta and CPU kernels, SURVEY.md
+# section 7 step 2).  The CUDA kernels validate, allocate with ATen and call the C ABI on torch's current stream; the Meta kernels give
+# shapes only (FakeTensor / torch.compile tracing of the drop-in modules); the CPU kernels refuse.  Rounds 1-3 registered the Python
+# functions above through torch.library; those stay as plain functions (`_logmel_impl` ...: tests and the raw launches of bench.py's legs).
+# No fallback: without the compiled library the package does not import.
+import os as _os_ops
+
+TORCH_LIB_PATH = _os_ops.path.join(_os_ops.path.dirname(_os_ops.path.abspath(__file__)), "libwakeword_amd_torch.so")
+if not _os_ops.path.exists(TORCH_LIB_PATH):
+    raise ImportError(f"{TORCH_LIB_PATH} is missing: build it with `make -C wakeword-jupyterlab_amd/csrc` "
+                      "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+torch.ops.load_library(TORCH_LIB_PATH)          # after _native loaded libwakeword_amd.so RTLD_GLOBAL: the operators bind to that copy
 
 
-def _no_cpu(name):
-    def impl(*args, **kwargs):
-        raise RuntimeError(f"wakeword_amd::{name}: no CPU implementation exists (HIP/gfx950 only); move the tensors to the GPU")
-    return impl
+# The public functions check argument types in Python first (TypeError / ValueError / NotImplementedError with the messages rounds 1-3
+# gave; the compiled kernels re-check with TORCH_CHECK -> RuntimeError), then dispatch: real tensors reach the HIP kernels, fake / meta
+# tensors the shape-only kernels.
+def _precheck_pcm(pcm) -> None:
+    _require_cuda_f32(pcm, "pcm")
+    if pcm.dim() != 2:
+        raise ValueError(f"pcm: expected [B, samples], got {tuple(pcm.shape)}")
+    if pcm.shape[1] == 0 or pcm.shape[1] > CLIP_SAMPLES:
+        raise ValueError(f"pcm: {pcm.shape[1]} samples per clip; the front-end takes 1..{CLIP_SAMPLES} "
+                         "(crop longer clips on the host, pad_or_truncate wakeword_training_script.py:78-83)")
 
 
-for _n in ("logmel", "cnn_pool", "lstm_fc", "cnn_lstm_forward", "forward_pcm"):
-    _lib.impl(_n, _no_cpu(_n), "CPU")
+def _precheck_x(x) -> None:
+    _require_cuda_f32(x, "x")
+    if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != N_MELS:
+        raise ValueError(f"x: expected [B, 1, {N_MELS}, T], got {tuple(x.shape)}")
+    if not 1 <= x.shape[3] <= 32:
+        raise NotImplementedError(f"x: T = {x.shape[3]} frames; the conv kernels are built for 1..32 (1 s clips give 32)")
 
 
 def logmel(pcm: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-    return torch.ops.wakeword_amd.logmel(pcm, normalize)
+    _precheck_pcm(pcm)
+    return torch.ops.wakeword_amd.logmel(pcm, bool(normalize))
 
 
 def cnn_pool(x, packed, n_conv):
+    _precheck_x(x)
+    _check_packed(packed, n_conv, x)
     return torch.ops.wakeword_amd.cnn_pool(x, packed, n_conv)
 
 
 def lstm_fc(pooled, packed, n_conv):
+    _require_cuda_f32(pooled, "pooled")
+    _check_packed(packed, n_conv, pooled)
+    if pooled.dim() != 2 or pooled.shape[1] != c_last(n_conv):
+        raise ValueError(f"pooled: expected [B, {c_last(n_conv)}], got {tuple(pooled.shape)}")
     return torch.ops.wakeword_amd.lstm_fc(pooled, packed, n_conv)
 
 
 def cnn_lstm_forward(x, packed, n_conv):
+    _precheck_x(x)
+    _check_packed(packed, n_conv, x)
     return torch.ops.wakeword_amd.cnn_lstm_forward(x, packed, n_conv)
 
 
 def forward_pcm(pcm, packed, n_conv, normalize: bool = True):
-    return torch.ops.wakeword_amd.forward_pcm(pcm, packed, n_conv, normalize)
+    _precheck_pcm(pcm)
+    _check_packed(packed, n_conv, pcm)
+    return torch.ops.wakeword_amd.forward_pcm(pcm, packed, n_conv, bool(normalize))
 
 
 # ------------------------------------------------------------------------------------------------
