@@ -141,10 +141,10 @@ def _load():
             f"{LIB_PATH} is missing: the HIP library is the only implementation of this path (no CPU "
             "fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C wakeword-jupyterlab_amd/csrc`.")
-    # RTLD_GLOBAL: libwakeword_amd_torch.so (the compiled torch.ops.wakeword_amd.* operators, ops.py) is built without linking this library
-    # and binds its ww_* calls to whichever copy is loaded here -- the shipped one, or an ablation / diagnostic build (WW_LIB_OVERRIDE).
-    # Only the C ABI is exported (-fvisibility=hidden), so nothing else enters the global scope.
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # RTLD_LOCAL (the default): nothing of this library enters the global symbol scope.  HIP kernel stubs have default visibility, so a
+    # globally loaded copy would interpose the kernels of every other build opened later in the process (scripts/ab_kernels.py opens
+    # several); libwakeword_amd_torch.so gets the addresses it needs from this handle instead (ops.py -> ww_torch_bind).
+    lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args

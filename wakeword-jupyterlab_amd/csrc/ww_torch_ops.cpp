@@ -3,8 +3,9 @@
 // torch.library (no Meta kernel: FakeTensor tracing / torch.compile of the drop-in modules could not work, and every call paid Python
 // dispatch); this translation unit replaces them.  It is host code only: it validates tensors, allocates outputs with ATen and calls
 //   ww_logmel_f32 / ww_cnn_pool_f32 / ww_lstm_fc_f32 / ww_model_forward_f32 / ww_forward_pcm_f32      (include/wakeword_amd.h)
-// on torch's current HIP stream.  The ww_* symbols are NOT linked at build time: the Python package loads libwakeword_amd.so (or the
-// build named by WW_LIB_OVERRIDE) with RTLD_GLOBAL first and this library binds to whichever copy that was.
+// on torch's current HIP stream.  The ww_* functions are neither linked nor looked up by name: the Python package hands their ADDRESSES in
+// (ww_torch_bind, from the ctypes handle of libwakeword_amd.so or of the build named by WW_LIB_OVERRIDE), so nothing enters the global
+// symbol scope -- several builds of the library can live in one process (scripts/ab_kernels.py) without interposing each other's kernels.
 //
 // Reference call sites these operators stand behind: AudioProcessor.audio_to_mel (wakeword_training_script.py:85-101) -> logmel;
 // SimpleWakewordModel.forward (wakeword_training/train_wakeword.py:38-49) / WakewordModel.forward (wakeword_training_script.py:167-184)
@@ -19,6 +20,33 @@
 namespace {
 
 constexpr int64_t kClip = WW_CLIP_SAMPLES, kMels = WW_N_MELS, kFrames = WW_N_FRAMES;
+
+// the C ABI entry points this library calls, bound once by ww_torch_bind (order = ops.py::_TORCH_BIND_ORDER)
+struct Abi {
+    decltype(&::ww_last_error) last_error = nullptr;
+    decltype(&::ww_packed_weights_floats) packed_weights_floats = nullptr;
+    decltype(&::ww_cnn_scratch_bytes) cnn_scratch_bytes = nullptr;
+    decltype(&::ww_workspace_bytes) workspace_bytes = nullptr;
+    decltype(&::ww_logmel_f32) logmel_f32 = nullptr;
+    decltype(&::ww_cnn_pool_f32) cnn_pool_f32 = nullptr;
+    decltype(&::ww_lstm_fc_f32) lstm_fc_f32 = nullptr;
+    decltype(&::ww_model_forward_f32) model_forward_f32 = nullptr;
+    decltype(&::ww_forward_pcm_f32) forward_pcm_f32 = nullptr;
+} abi;
+constexpr int kAbiEntries = 9;
+const Abi& bound() {
+    TORCH_CHECK(abi.forward_pcm_f32 != nullptr, "wakeword_amd: the operators are not bound to libwakeword_amd.so (import wakeword_jupyterlab_amd does it)");
+    return abi;
+}
+#define ww_last_error bound().last_error
+#define ww_packed_weights_floats bound().packed_weights_floats
+#define ww_cnn_scratch_bytes bound().cnn_scratch_bytes
+#define ww_workspace_bytes bound().workspace_bytes
+#define ww_logmel_f32 bound().logmel_f32
+#define ww_cnn_pool_f32 bound().cnn_pool_f32
+#define ww_lstm_fc_f32 bound().lstm_fc_f32
+#define ww_model_forward_f32 bound().model_forward_f32
+#define ww_forward_pcm_f32 bound().forward_pcm_f32
 
 void* stream_of(const at::Tensor& t) { return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream()); }
 
@@ -168,6 +196,34 @@ at::Tensor cnn_lstm_forward_cpu(const at::Tensor&, const at::Tensor&, int64_t) {
 at::Tensor forward_pcm_cpu(const at::Tensor&, const at::Tensor&, int64_t, bool) { no_cpu("forward_pcm"); }
 
 }  // namespace
+
+#undef ww_last_error
+#undef ww_packed_weights_floats
+#undef ww_cnn_scratch_bytes
+#undef ww_workspace_bytes
+#undef ww_logmel_f32
+#undef ww_cnn_pool_f32
+#undef ww_lstm_fc_f32
+#undef ww_model_forward_f32
+#undef ww_forward_pcm_f32
+
+// fns[kAbiEntries]: addresses of ww_last_error, ww_packed_weights_floats, ww_cnn_scratch_bytes, ww_workspace_bytes, ww_logmel_f32,
+// ww_cnn_pool_f32, ww_lstm_fc_f32, ww_model_forward_f32, ww_forward_pcm_f32 of ONE build of libwakeword_amd.so.  Returns 0, or -1 on a bad table.
+extern "C" __attribute__((visibility("default"))) int ww_torch_bind(const void* const* fns, int n) {
+    if (!fns || n != kAbiEntries) return -1;
+    for (int i = 0; i < n; ++i)
+        if (!fns[i]) return -1;
+    abi.last_error = reinterpret_cast<decltype(abi.last_error)>(const_cast<void*>(fns[0]));
+    abi.packed_weights_floats = reinterpret_cast<decltype(abi.packed_weights_floats)>(const_cast<void*>(fns[1]));
+    abi.cnn_scratch_bytes = reinterpret_cast<decltype(abi.cnn_scratch_bytes)>(const_cast<void*>(fns[2]));
+    abi.workspace_bytes = reinterpret_cast<decltype(abi.workspace_bytes)>(const_cast<void*>(fns[3]));
+    abi.logmel_f32 = reinterpret_cast<decltype(abi.logmel_f32)>(const_cast<void*>(fns[4]));
+    abi.cnn_pool_f32 = reinterpret_cast<decltype(abi.cnn_pool_f32)>(const_cast<void*>(fns[5]));
+    abi.lstm_fc_f32 = reinterpret_cast<decltype(abi.lstm_fc_f32)>(const_cast<void*>(fns[6]));
+    abi.model_forward_f32 = reinterpret_cast<decltype(abi.model_forward_f32)>(const_cast<void*>(fns[7]));
+    abi.forward_pcm_f32 = reinterpret_cast<decltype(abi.forward_pcm_f32)>(const_cast<void*>(fns[8]));
+    return 0;
+}
 
 TORCH_LIBRARY(wakeword_amd, m) {
     m.def("logmel(Tensor pcm, bool normalize=True) -> Tensor");

@@ -194,6 +194,7 @@ def _forward_pcm_impl(pcm: torch.Tensor, packed: torch.Tensor, n_conv: int, norm
 # section 7 step 2).  The CUDA kernels validate, allocate with ATen and call the C ABI on torch's current stream; the Meta kernels give
 # shapes only (FakeTensor / torch.compile tracing of the drop-in modules); the CPU kernels refuse.  Rounds 1-3 registered the Python
 # functions above through torch.library; those stay as plain functions (`_logmel_impl` ...: tests and the raw launches of bench.py's legs).
+# The library does not link libwakeword_amd.so: it is handed the addresses of the nine C ABI functions it calls.
 # No fallback: without the compiled library the package does not import.
 import os as _os_ops
 
@@ -201,7 +202,14 @@ TORCH_LIB_PATH = _os_ops.path.join(_os_ops.path.dirname(_os_ops.path.abspath(__f
 if not _os_ops.path.exists(TORCH_LIB_PATH):
     raise ImportError(f"{TORCH_LIB_PATH} is missing: build it with `make -C wakeword-jupyterlab_amd/csrc` "
                       "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
-torch.ops.load_library(TORCH_LIB_PATH)          # after _native loaded libwakeword_amd.so RTLD_GLOBAL: the operators bind to that copy
+torch.ops.load_library(TORCH_LIB_PATH)
+# bind the operators to THE copy of libwakeword_amd.so this process uses (the shipped one or a WW_LIB_OVERRIDE build): addresses, not names
+_TORCH_BIND_ORDER = ("ww_last_error", "ww_packed_weights_floats", "ww_cnn_scratch_bytes", "ww_workspace_bytes", "ww_logmel_f32",
+                     "ww_cnn_pool_f32", "ww_lstm_fc_f32", "ww_model_forward_f32", "ww_forward_pcm_f32")
+_torch_lib = C.CDLL(TORCH_LIB_PATH)
+_table = (C.c_void_p * len(_TORCH_BIND_ORDER))(*[C.cast(getattr(nat.lib, _n), C.c_void_p).value for _n in _TORCH_BIND_ORDER])
+if _torch_lib.ww_torch_bind(_table, len(_TORCH_BIND_ORDER)) != 0:
+    raise ImportError("libwakeword_amd_torch.so refused the C ABI table (rebuild: make -C wakeword-jupyterlab_amd/csrc)")
 
 
 # The public functions check argument types in Python first (TypeError / ValueError / NotImplementedError with the messages rounds 1-3
