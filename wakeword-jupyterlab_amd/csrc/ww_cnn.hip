@@ -704,6 +704,24 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t uniform_value, uint32_t 
 #endif
     return reg;
 }
+// The eight ballots of a column half (rows 0 / 1 x register j) -> lanes 0..15 of one register: 16 v_writelane behind ONE pair of wait
+// states (round 4; round 3 issued each v_writelane behind its own `s_nop 1`: 30 more scalar instructions per tile row and wave of the
+// training forwards).  The ballots are written by v_cmp long before this block; the s_nop covers the last of them.
+__device__ __forceinline__ uint32_t ballots_to_lanes(const unsigned long long (&live0)[4], const unsigned long long (&live1)[4]) {
+    uint32_t word = 0u;
+    asm volatile("s_nop 1\n\t"
+                 "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+                 "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11\n\t"
+                 "v_writelane_b32 %0, %13, 12\n\tv_writelane_b32 %0, %14, 13\n\tv_writelane_b32 %0, %15, 14\n\tv_writelane_b32 %0, %16, 15"
+                 : "+v"(word)
+                 : "s"(uint32_t(live0[0])), "s"(uint32_t(live0[0] >> 32)), "s"(uint32_t(live0[1])), "s"(uint32_t(live0[1] >> 32)),
+                   "s"(uint32_t(live0[2])), "s"(uint32_t(live0[2] >> 32)), "s"(uint32_t(live0[3])), "s"(uint32_t(live0[3] >> 32)),
+                   "s"(uint32_t(live1[0])), "s"(uint32_t(live1[0] >> 32)), "s"(uint32_t(live1[1])), "s"(uint32_t(live1[1] >> 32)),
+                   "s"(uint32_t(live1[2])), "s"(uint32_t(live1[2] >> 32)), "s"(uint32_t(live1[3])), "s"(uint32_t(live1[3] >> 32)));
+    return word;
+}
+
 // ------------------------------------------------------------------------------------------------
 // cnn2w_kernel: conv1 + conv2 + ReLU + pool with conv2 as a ONE-DIMENSIONAL WINOGRAD F(2,3) along the image rows
 // (split precision, v_mfma_f32_16x16x32_f16 x3): two output rows (2t, 2t+1) of a "tile row" t come from the four
@@ -1038,6 +1056,7 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                     }
                 }
                 if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
+#ifdef WW_ABL_WRITELANE_EACH      // A/B: round 3's form, every v_writelane behind its own wait states
                     uint32_t word = 0u;
                     word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
                     word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
@@ -1047,6 +1066,9 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                     word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
                     word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
                     word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
+#else
+                    const uint32_t word = ballots_to_lanes(live0, live1);
+#endif
                     if (lane < 16) {
                         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
                         reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16) + lane] = word;
@@ -1590,6 +1612,8 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
                 // the eight ballots of (row r, register j) go out as they are: 64 contiguous bytes per (tile row, N-tile, column half) =
                 // [r][j] x 64 bits, bit 16 kq + pi <-> column 16 c + 4 kq + j, channel 16 nt + pi.  v_writelane moves each half into
                 // lane 2 (4 r + j) + half of one register: 16 scalar-to-lane moves and ONE 4-byte store by 16 lanes.
+#if 1       // one v_writelane per wait-state pair here: the single block of cnn2w_kernel<2> (ballots_to_lanes) measured 2.5 % SLOWER in this
+            // kernel (3-conv training step 6.00 vs 5.85 ms): sixteen scalar operands live at once at its 256-register cap
                 uint32_t word = 0u;
                 word = write_lane<0>(uint32_t(live0[0]), word);  word = write_lane<1>(uint32_t(live0[0] >> 32), word);
                 word = write_lane<2>(uint32_t(live0[1]), word);  word = write_lane<3>(uint32_t(live0[1] >> 32), word);
@@ -1599,6 +1623,9 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
                 word = write_lane<10>(uint32_t(live1[1]), word); word = write_lane<11>(uint32_t(live1[1] >> 32), word);
                 word = write_lane<12>(uint32_t(live1[2]), word); word = write_lane<13>(uint32_t(live1[2] >> 32), word);
                 word = write_lane<14>(uint32_t(live1[3]), word); word = write_lane<15>(uint32_t(live1[3] >> 32), word);
+#else
+                const uint32_t word = ballots_to_lanes(live0, live1);
+#endif
                 if (lane < 16) {
                     const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
                     reinterpret_cast<uint32_t*>(bits3)[((((clip * kWTileRows + t) * 8 + nt) * 2 + c) * 16) + lane] = word;
