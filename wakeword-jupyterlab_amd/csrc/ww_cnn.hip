@@ -1009,23 +1009,6 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
 #ifndef WW_ABL_X_NORING
             flag_signal(&free_cnt[b]);                       // the buffer is free as soon as its fragments are in the accumulators
 #endif
-#ifdef WW_ABL_FAKEPROD      // timing-only (with -DWW_ABL_NOPROD): a quarter of a producer's tile row of vector work and LDS stores in every consumer wave
-            {
-                float f[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) f[i] = acc[i & 3][(i >> 2) & 1][i >> 3] + float(i);
-#pragma unroll
-                for (int rnd = 0; rnd < WW_ABL_FAKEPROD; ++rnd)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) f[i] = fmaf(f[i], 1.0001f, f[(i + 5) & 15]);
-                char* dump = reinterpret_cast<char*>(melh0) + (wave * 64 + lane) * 16;       // the log-mel planes: unused in this ablation
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = {f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
-                    *reinterpret_cast<f32x4*>(dump + i * 8192) = v;
-                }
-            }
-#endif
             // output transform + bias + 2*relu + pool (D: lane & 15 = channel, register j <-> column 16 c + 4 kq + j)
             const int trow = kWPerProd * (2 * grp + (sq & 1)) + (sq >> 1);      // the tile row this step holds (producer 2 grp + (sq & 1), its i-th)
             float pv[8];                                        // the tile row's eight (v0 + v1) pairs: summed as a tree, then into `pool`
