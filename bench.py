@@ -477,7 +477,7 @@ def main():
             # K0 alone, and WAV files -> logits
             import bench_files
             out["decode"] = bench_files.measure_decode(batch=B, steps=10, device=dev.index)
-            out["file_pipeline"] = bench_files.measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=dev.index)
+            out["file_pipeline"] = bench_files.measure_file_pipeline(n_files=4096, batch=1024, passes=256, device=dev.index)   # one stream of 1 M files (~1 s: ten quota periods)
         print(json.dumps(out))
     if pipe.active:
         dist.barrier()

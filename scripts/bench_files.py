@@ -68,7 +68,16 @@ def measure_decode(batch=4096, steps=10, device=0):
     return out
 
 
-def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=None, tmp_root=None):
+def _cgroup_cpu_stat():
+    """usage_usec / nr_periods / nr_throttled / throttled_usec of this process's cgroup (v2), {} where there is none."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            return {k: int(v) for k, v in (line.split() for line in f)}
+    except (OSError, ValueError):
+        return {}
+
+
+def measure_file_pipeline(n_files=4096, batch=1024, passes=256, device=0, threads=None, tmp_root=None):
     """WAV files -> logits, end to end, page cache warm (the files were just written)."""
     import wakeword_jupyterlab_amd as pkg
     from wakeword_jupyterlab_amd import files as files_mod
@@ -95,38 +104,43 @@ def measure_file_pipeline(n_files=4096, batch=1024, passes=6, device=0, threads=
         n_b = n_files // batch
         logits = [torch.empty((batch, 2), device=dev) for _ in range(n_b)]
 
-        def one_pass(timing=None):
+        def stream(enc_, timing=None):
             t_prev = time.perf_counter()
-            for b, (buf, ok) in enumerate(rd.stream(enc, batch, normalize=True, verbose=False)):     # reader thread one batch ahead
+            for b, (buf, ok) in enumerate(rd.stream(enc_, batch, normalize=True, verbose=False)):     # reader thread one batch ahead
                 t1 = time.perf_counter()
                 with torch.no_grad():
-                    logits[b].copy_(m.forward_pcm(buf, normalize=False))         # K0 already normalised over the whole file
+                    logits[b % n_b].copy_(m.forward_pcm(buf, normalize=False))   # K0 already normalised over the whole file
                 if timing is not None:
                     timing[0] += t1 - t_prev                                      # waiting for the reader + upload / K0 enqueue
                     timing[1] += time.perf_counter() - t1
                 t_prev = time.perf_counter()
                 assert ok.all()
-        one_pass()
+        stream(enc)
         torch.cuda.synchronize(dev)
         first = torch.cat(logits).clone()
+        # ONE stream over `passes` repetitions of the file list: an epoch is one long stream, and the host's CPU quota (cgroup cpu.max)
+        # is enforced per 100 ms period -- a run shorter than a few periods measures a burst the quota has not caught up with yet
+        long_enc = EncodedPaths(paths * passes)
         timing = [0.0, 0.0]
+        cpu0 = _cgroup_cpu_stat()
         t0 = time.perf_counter()
-        for _ in range(passes):
-            one_pass(timing)
+        stream(long_enc, timing)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
+        cpu1 = _cgroup_cpu_stat()
         same = bool(torch.equal(first, torch.cat(logits)))
-        # the host side alone (read into staging, no GPU work queued behind it)
+        # the host side alone (read into staging, no GPU work queued behind it), over the same number of files
         t1 = time.perf_counter()
-        for _ in range(2):
-            for b in range(n_b):
-                rd.read(enc, b % 3, b * batch, (b + 1) * batch)
-        host_dt = (time.perf_counter() - t1) / 2
+        for b in range(n_b * passes):
+            rd.read(long_enc, b % 3, b * batch, (b + 1) * batch)
+        host_dt = (time.perf_counter() - t1) / passes
         rd.close()
         n = n_files * passes
         return {"workload": f"{n_files} WAV files (1 s, 16 kHz, PCM-16, {file_bytes} B each; create_sample_data's format) in a temporary directory, page cache warm "
                             f"-> logits: library reader threads (driven one batch ahead by a helper thread: WavBatchReader.stream) -> pinned staging -> H2D (copy stream) -> K0 -> K1 -> K2 -> K3, batches of {batch}, 3 staging slots, "
-                            f"SimpleWakewordModel; {passes} passes over the files",
+                            f"SimpleWakewordModel; one stream over {passes} repetitions of the file list ({n_files * passes} files, {dt:.2f} s: many periods of the host's CPU quota)",
+                "seconds": dt, "host_cpus_used": (cpu1["usage_usec"] - cpu0["usage_usec"]) * 1e-6 / dt if cpu0 else None,
+                "quota_periods_throttled": [cpu1["nr_throttled"] - cpu0["nr_throttled"], cpu1["nr_periods"] - cpu0["nr_periods"]] if cpu0 else None,
                 "clips_per_s": n / dt, "ms_per_batch": 1e3 * dt / (n_b * passes), "host_threads": threads, "host_cpus": os.cpu_count(), "host_cpu_share_of_this_rank": files_mod.host_cpu_share(),
                 "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1),
                 "host_read_only_clips_per_s": n_files / host_dt, "main_thread_ms_waiting_for_reader_per_batch": 1e3 * timing[0] / (n_b * passes),

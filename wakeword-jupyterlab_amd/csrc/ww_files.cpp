@@ -10,7 +10,9 @@
 // Order inside the staging buffer is first-come (an atomic bump allocator): descriptors carry the byte offsets, so the
 // layout does not matter and no second pass over the files is needed.
 #include <fcntl.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -25,6 +27,10 @@
 #include <vector>
 
 #include "ww_internal.h"
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 
 namespace ww {
 
@@ -164,6 +170,30 @@ struct ww_wav_reader {
 
 namespace ww {
 
+// Payload -> pinned staging.  The staging slots (3 x 33 MB at the bench's size) live in DRAM and the next reader of these bytes is the
+// copy engine, not a CPU: streaming stores write the lines without first reading them for ownership and without evicting the page
+// cache's lines the next read() wants (same host, 16 threads, open + read + copy + close: 3.1-3.3 -> 2.65-2.70 ms per 4096 files on
+// the container's overlay, 2.30 -> 1.70 on tmpfs; scripts/proto/reader_micro.c modes 2 / 4).  dst is 16-byte aligned (the allocator).
+static void copy_to_staging(uint8_t* dst, const uint8_t* src, size_t n) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    size_t i = 0;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && n >= 256) {
+        for (; i + 64 <= n; i += 64) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
+            const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32));
+            const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a);
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c);
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
+        }
+        _mm_sfence();                                          // before the batch is handed on (the caller's thread starts the upload)
+    }
+    std::memcpy(dst + i, src + i, n - i);
+#endif
+}
+
 static void read_one(Job* j, int64_t i, uint8_t* win) {
     ww_clip_desc d;
     std::memset(&d, 0, sizeof d);
@@ -190,7 +220,7 @@ static void read_one(Job* j, int64_t i, uint8_t* win) {
                     int64_t got = 0;
                     if (w.data_start < win_len) {
                         got = win_len - w.data_start < bytes ? win_len - w.data_start : bytes;
-                        std::memcpy(dst, win + w.data_start, size_t(got));
+                        copy_to_staging(dst, win + w.data_start, size_t(got));
                     }
                     while (got < bytes) {
                         const ssize_t r = pread(fd, dst + got, size_t(bytes - got), off_t(w.data_start + got));
@@ -215,7 +245,30 @@ static void read_range(Job* j) {
     for (int64_t i; (i = j->next.fetch_add(1, std::memory_order_relaxed)) < j->n;) read_one(j, i, win);
 }
 
+// What a pool thread shares with the rest of the process decides the reader's rate: with 16+ threads opening ~1 M files/s, every
+// open() / close() takes the lock of the process's descriptor table and bumps the reference count of the process's credentials --
+// two cache lines that all threads fight over (MI355X host, 16-CPU quota, scripts/proto/reader_micro.c, open + read + copy + close
+// from 16 threads: 0.81 M files/s as the process comes, 1.02 M on private descriptor tables, 1.33 M with private credentials too).
+// Each pool thread therefore leaves both behind:
+//  * close_range(3, ~0, CLOSE_RANGE_UNSHARE): an empty descriptor table of its own (0-2 are copied, nothing else: the thread holds
+//    no reference to the process's sockets or device nodes -- closing one elsewhere still closes it -- and what it opens is its
+//    own).  A pool thread never uses a descriptor it did not open itself.
+//  * prctl(PR_SET_KEEPCAPS, <the value it has>): changes nothing, but the call commits a copy of the credentials to this thread --
+//    the same identity in an object of its own, so open()'s get_cred() no longer bounces a line between CPUs.
+// Kernels without close_range (< 5.9) or a seccomp filter that denies either call: the thread keeps what it shares, nothing else
+// changes.  WW_READER_SHARED_FDS=1 keeps both shared (ThreadSanitizer tracks descriptors by number for the whole process).
+static void leave_shared_process_state() {
+    static const bool keep = getenv("WW_READER_SHARED_FDS") != nullptr;
+    if (keep) return;
+#ifdef SYS_close_range
+    (void)syscall(SYS_close_range, 3u, ~0u, 2u /* CLOSE_RANGE_UNSHARE */);
+#endif
+    const int keepcaps = prctl(PR_GET_KEEPCAPS, 0, 0, 0, 0);
+    if (keepcaps >= 0) (void)prctl(PR_SET_KEEPCAPS, keepcaps, 0, 0, 0);
+}
+
 static void worker_main(ww_wav_reader* r) {
+    leave_shared_process_state();
     uint64_t seen = 0;
     for (;;) {
         Job* j;

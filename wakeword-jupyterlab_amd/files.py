@@ -48,13 +48,16 @@ def host_cpu_share() -> int:
 
 
 def default_threads() -> int:
-    """Host threads of a reader: TWICE this rank's CPU share (host_cpu_share), at most 32 -- a reader thread spends part of its time
-    blocked in open / pread, and on an MI355X box (quota 16 CPUs) 32 threads fed the pipeline 5 % faster than 16 while 64 thrashed
-    against the quota (`profiles/r04_reader_threads.json`) -- or WW_READER_THREADS."""
+    """Host threads of a reader: this rank's CPU share (host_cpu_share), at most 32, or WW_READER_THREADS.  A reader thread is busy the
+    whole time a batch is being read (page cache warm: open / pread / close are CPU work, not waiting), so threads beyond the share
+    only spend the cgroup's quota faster and are throttled for the rest of each 100 ms period: on an MI355X box (quota 16 CPUs), one
+    stream over 0.5 M files, 12 / 16 / 24 / 32 / 48 threads fed the pipeline at 0.87-0.90 / 0.87-0.96 / 0.84-0.88 / 0.69-0.74 /
+    0.58-0.63 M clips/s (`profiles/r04_reader_threads_sustained.txt`; round 3's "32 beats 16" came from runs shorter than one quota
+    period)."""
     env = os.environ.get("WW_READER_THREADS")
     if env:
         return max(1, min(256, int(env)))
-    return max(1, min(32, 2 * host_cpu_share()))
+    return max(1, min(32, host_cpu_share()))
 
 
 class EncodedPaths:
@@ -261,10 +264,10 @@ class WavBatchReader:
             stop.set()
             while t.is_alive():                      # drain so that a producer blocked on put() can finish
                 try:
-                    q.get(timeout=0.05)
+                    q.get_nowait()
                 except queue.Empty:
                     pass
-            t.join()
+                t.join(0.001)                        # (a blocking get(timeout) here could sleep its whole timeout after the thread had gone)
             self._streaming = False
 
     def regrow(self, max_clips: int, max_raw_bytes: int) -> None:
