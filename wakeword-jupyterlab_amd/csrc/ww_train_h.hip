@@ -721,14 +721,14 @@ __global__ __launch_bounds__(256) void reduce_wgrad3_h_kernel(const float* __res
 //   D[m = column][n = ci] += A[m][k] B[k][n] on v_mfma_f32_16x16x32_f16, k = 32 of the 64 co of one tap:
 //   A = mask2 at the shifted position (exact 0/1, one ds_read_b128 of the channels-last record), B = G 2^-eg as hi + lo: two MFMAs.
 //   dz1 = da1 * [relu(conv1) > 0]  (the forward's sign bits);  dW1[ci][t] = sum_pos dz1[ci][pos] * mel[pos + t],  db1 = sum dz1
-//   as v_mfma_f64_16x16x4_f64 (M = ci, N = the 9 taps + a column of ones, K = four positions): a conv1 weight gradient is a sum of
-//   ~10^5 products with heavy cancellation -- double accumulation, now on the matrix pipe instead of 18 vector instructions per element.
+//   as one more split-precision block per row (M = ci, N = the 9 taps + a column of ones, K = the row's 32 positions; see the
+//   epilogue): a conv1 weight gradient is a sum of ~10^7 products with heavy cancellation -- float inside one clip (2560 positions),
+//   double across clips.
 // 8 waves (256 VGPRs each) = (16 ci) x (row of a four-row step); the wave's 18 k-steps x (hi, lo) = 144 B-operand VGPRs are rebuilt
 // at the start of every clip from the pre-ordered fp32 weights (L1/L2) times the clip's gp, scaled by 2^-eg (eg from max|gp[b]| max|W2|).
 // All 512 threads fill the next step's mask rows (bit image -> LUT -> 160-byte records) and conv1 sign rows; one barrier per step.
 // Output: one partial [32][9] + [32] (float; summed over the workgroup in double) per workgroup -> reduce_partials_kernel.
 // ------------------------------------------------------------------------------------------------
-typedef double double4v __attribute__((ext_vector_type(4)));
 // DENSE (the 3-conv model's conv2): A = dz2 pre-split by conv3_dgrad_h_kernel (f16 records [64 hi | 64 lo], 288 bytes in LDS), B = W2 2^-ew
 // as hi + lo built ONCE per launch, three MFMAs per block (A_hi B_hi + A_hi B_lo + A_lo B_hi), da1 = 2^(ew + edz) x the accumulator.
 template <bool DENSE>
@@ -785,9 +785,11 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
     uint32_t* s1rows = reinterpret_cast<uint32_t*>(ldsb + L::kOffS1);
     u32x4* lut = reinterpret_cast<u32x4*>(ldsb + L::kOffLut);
 
+    __shared__ uint32_t melmax[2];                                  // float bits of max |mel| of clip k at [k & 1]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = wave & 1, rg = wave >> 1;                       // 16 ci x row of the step
+    if (tid == 0) { melmax[0] = 0u; melmax[1] = 0u; }
     const int ln = lane & 15, grp = lane >> 4;
     const int my_clips = (n - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);
     const int total = my_clips * kHSteps;
@@ -800,12 +802,25 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
         for (int d = 0; d < 4; ++d) m[d] = ((tid >> (2 * d)) & 1 ? 0x3c00u : 0u) | ((tid >> (2 * d + 1)) & 1 ? 0x3c000000u : 0u);
         lut[tid] = m;
     }
-    auto load_mel = [&](int k) {
+    auto load_mel = [&](int k) {                                    // + the clip's max |mel| (the exponent of its f16 image in the epilogue)
         const float* src = mel + (int64_t(blockIdx.x) + int64_t(k) * gridDim.x) * kTH * width;
         float* melt = meltile + (k & 1) * L::kMelFloats;
+        float mx = 0.f;
         for (int i = tid; i < kTH * width; i += 512) {
             const int y = i / width, xx = i - y * width;
-            melt[(y + 1) * L::kMelRS + xx + 1] = src[i];
+            const float v = src[i];
+            melt[(y + 1) * L::kMelRS + xx + 1] = v;
+            mx = fmaxf(mx, __builtin_fabsf(v));
+        }
+        atomicMax(&melmax[k & 1], __float_as_uint(mx));
+    };
+    auto mel_exp = [&](int k) { return clampi(exp_of(__uint_as_float(melmax[k & 1])) - 14, -100, 100); };      // |mel| 2^-em < 2^15
+    auto scale_mel = [&](int k) {                                   // a barrier after load_mel(k): the tile becomes mel 2^-em (f16 range)
+        float* melt = meltile + (k & 1) * L::kMelFloats;
+        const float down = pow2i(-mel_exp(k));
+        for (int i = tid; i < kTH * width; i += 512) {
+            const int y = i / width, xx = i - y * width;
+            melt[(y + 1) * L::kMelRS + xx + 1] *= down;
         }
     };
     // the rows a step needs beyond what is already in LDS: mask rows 0..4 (first step of a clip) or 4s+1..4s+4, conv1 sign rows 4s..4s+3
@@ -857,18 +872,24 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
         }
         if (tid < kHRows * kTW) s1rows[(gs & 1) * kHRows * kTW + tid] = sw_next;
         if (s == 8 && k + 1 < my_clips) load_mel(k + 1);
+        if (s == 12 && k + 1 < my_clips) scale_mel(k + 1);
     };
 
     // B operand of this wave: G[k-step][hi, lo], rebuilt per clip
     half8 bh[18], bl[18];
-    double4v dacc = {0., 0., 0., 0.};                               // dW1 / db1: row (register j) ci = 4 j + grp, column (lane & 15) = tap, 9 = bias
-    float dscale = 0.f;
+    // dW1 / db1: row (register j) ci = 16 nt + 4 grp + j, column (lane & 15) = tap, 9 = bias: one clip in float (cacc), all clips in double
+    double dacc[4] = {0., 0., 0., 0.};
+    f32x4 cacc = {0.f, 0.f, 0.f, 0.f};
+    // dz1 in the accumulator's units is below 576 x 2^13 (!DENSE: G 2^-eg < 2^13) or 576 x 2^14 x 2^13 (DENSE: records < 2^14): scaled into f16
+    constexpr float kDzDown = DENSE ? 0x1p-22f : 0x1p-10f;
+    float dscale = 0.f, mel_up = 1.f;
     auto rebuild = [&](int k) {
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
         // !DENSE: G = gp[b] W2 2^-eg, per clip.  DENSE: W2 2^-ew once (k == 0), the clip only changes the descale 2^(ew + edz)
         const int eg = clampi(exp_of((DENSE ? 1.0f : gpmax[clip]) * w2max[0]) - 12, -100, 100);
         const float down = pow2i(-eg);
         dscale = DENSE ? pow2i(eg) * gpmax[clip] : pow2i(eg);
+        mel_up = pow2i(mel_exp(k));
         if (DENSE && k > 0) return;
         float gv[16];
 #pragma unroll
@@ -900,6 +921,7 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
     load_mel(0);
     if (total > 0) fill_load(0);
     __syncthreads();                                               // the LUT is complete
+    if (total > 0) scale_mel(0);
     if (total > 0) fill_store(0);
     __syncthreads();
     const char* abase = gring + (ln + 1) * L::kGRec + grp * 16;       // A: row = column ln of the m-tile, k = 8 channels of the lane group
@@ -950,21 +972,42 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
             if constexpr (DENSE) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[it % RING], bh[ks], acc[mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // epilogue: D register j <-> column 16 mt + 4 grp + j, lane & 15 <-> ci = 16 nt + ln
+        // epilogue: D register j <-> column 16 mt + 4 grp + j, lane & 15 <-> ci = 16 nt + ln.  That IS the A-operand layout of a
+        // 16x16x32 block (m = ci, the lane group's eight k = its eight columns 4 grp + 0..3, 16 + 4 grp + 0..3), so the row's
+        // dW1 / db1 contribution is one k = 32 block: A = dz1 2^-down as hi + lo, B[k][n = tap] = mel at the same eight columns
+        // shifted by the tap (n = 9: ones -> db1) as hi + lo, three MFMAs into a float tile that lives for ONE clip (2560 positions)
+        // and is then added to the double sums.  (Round 3 ran eight v_mfma_f64_16x16x4 per row here: 64 matrix-pipe cycles each on
+        // this part, 30 % of the kernel's pipe time, issued as one dependent chain behind every step.)
         const float* melt = meltile + (k & 1) * L::kMelFloats;
         const uint32_t* s1 = s1rows + ((gs & 1) * kHRows + rg) * kTW;
         const int tap = ln, ty = tap / 3, tx = tap - 3 * ty;
         const float* mp = melt + (y + ty) * L::kMelRS + tx;           // + column: taps of position (y, col) are tile rows y..y+2, columns col..col+2
+        u32x4 ah, al, mh, ml;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const u32x4 sw = *reinterpret_cast<const u32x4*>(s1 + 16 * mt + 4 * grp);
 #pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const int col = 16 * mt + 4 * grp + 2 * jp;
+                const float a0 = ((sw[2 * jp] >> (16 * nt + ln)) & 1u) ? acc[mt][2 * jp] * kDzDown : 0.f;
+                const float a1 = ((sw[2 * jp + 1] >> (16 * nt + ln)) & 1u) ? acc[mt][2 * jp + 1] * kDzDown : 0.f;
+                const float m0 = tap < 9 ? mp[col] : (tap == 9 ? 1.0f : 0.f);
+                const float m1 = tap < 9 ? mp[col + 1] : (tap == 9 ? 1.0f : 0.f);
+                uint32_t hh, ll;
+                split2(a0, a1, hh, ll); ah[2 * mt + jp] = hh; al[2 * mt + jp] = ll;
+                split2(m0, m1, hh, ll); mh[2 * mt + jp] = hh; ml[2 * mt + jp] = ll;
+            }
+        }
+        cacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, mh), cacc, 0, 0, 0);
+        cacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, ml), cacc, 0, 0, 0);
+        cacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al), __builtin_bit_cast(half8, mh), cacc, 0, 0, 0);
+        if (s == kHSteps - 1) {                                        // the clip's tile -> the double sums, with the clip's scale
+            const double up = double(dscale) * double(1.0f / kDzDown) * double(tap < 9 ? mel_up : 1.0f);
+            if (tid == 0) melmax[k & 1] = 0u;                          // read at s == 0 (rebuild), next written by load_mel(k + 2) at step 8 of clip k + 1
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int col = 16 * mt + 4 * grp + j;
-                const bool live = (sw[j] >> (16 * nt + ln)) & 1u;
-                const double a64 = live ? double(acc[mt][j] * dscale) : 0.0;
-                const float mv = tap < 9 ? mp[col] : (tap == 9 ? 1.0f : 0.f);
-                dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a64, double(mv), dacc, 0, 0, 0);
+                dacc[j] += double(cacc[j]) * up;
+                cacc[j] = 0.f;
             }
         }
         if (gs + 1 < total) fill_store(gs + 1);
@@ -982,7 +1025,7 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
             double sum = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) sum += red[((2 * r + nt) * 4 + j) * 64 + lane];
-            const int ci = 16 * nt + 4 * j + grp;
+            const int ci = 16 * nt + 4 * grp + j;
             if (ln < 9) outp[ci * 9 + ln] = float(sum);
             else outp[L::CIN * 9 + ci] = float(sum);
         }
