@@ -771,7 +771,11 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                                                        const float* __restrict__ b2, const float* __restrict__ rng,
                                                        float* __restrict__ out, float* __restrict__ apow2, uint16_t* __restrict__ bits,
                                                        uint16_t* __restrict__ bits1) {
+#ifdef WW_ABL_NOBITS            // timing-only ablations of the training forward: 1 = no conv2 mask image, 2 = no conv1 sign image either
+    constexpr bool POOL = OUT == 1 || OUT == 2, BITS = false, BITS1 = WW_ABL_NOBITS < 2 && (OUT == 2 || OUT == 3);
+#else
     constexpr bool POOL = OUT == 1 || OUT == 2, BITS = OUT == 2, BITS1 = OUT == 2 || OUT == 3;
+#endif
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     char* act0 = ldsb;
     _Float16* melh0 = reinterpret_cast<_Float16*>(ldsb + kWNB * kWBuf);      // 2 clips x (hi plane, lo plane) of [82][36] f16
