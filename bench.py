@@ -464,11 +464,11 @@ def main():
             out["augmentation"] = bench_augment.measure(batch=B, steps=5, check=4, device=dev.index)
             # one training step of the same model (forward in train mode + backward + Adam)
             import bench_train
-            out["training"] = bench_train.measure(batch=B, steps=5, device=dev.index)
+            out["training"] = bench_train.measure(batch=B, steps=20, device=dev.index)
             out["training"]["exact_fp32_ms_per_step"] = bench_train.measure(batch=B, steps=3, device=dev.index, math="f32", cpu_sample=8)["ms_per_step"]
             bench_train.ops_reset_train_math()
             out["training_pipeline"] = bench_train.measure_pipeline(batch=B, steps=3, device=dev.index)
-            out["training_3conv"] = bench_train.measure(batch=2048, steps=3, device=dev.index, arch="full", cpu_sample=16)
+            out["training_3conv"] = bench_train.measure(batch=2048, steps=10, device=dev.index, arch="full", cpu_sample=16)
             out["training_3conv"]["exact_fp32_ms_per_step"] = bench_train.measure(batch=2048, steps=2, device=dev.index, arch="full", math="f32", cpu_sample=4)["ms_per_step"]
             bench_train.ops_reset_train_math()
             # the notebook's model in inference (driver-run figure for SURVEY A11 / 8(f).3's forward half)

@@ -34,7 +34,7 @@ def measure(batch=4096, steps=5, device=0, cpu_sample=64, arch="simple", math=No
         loss.backward()
         opt.step()
         return loss
-    for _ in range(2):
+    for _ in range(5):           # allocator, clocks, lazily created optimizer state: the third to fifth step still run 5-8 % slow (scripts/proto/train_steps.py)
         step()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
