@@ -1038,8 +1038,14 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
                         o[kW * 64] = col_live ? 0.5f * v1 : 0.f;
                     }
                     if constexpr (BITS) {       // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
-                        live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
-                        live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
+                        // the column mask is ANDed in as a scalar: ballot(col_live && v > 0) is lowered to v_cndmask + v_cmp_ne behind
+                        // the compare (two more vector instructions per ballot, 32 per tile row)
+                        // (nor as ballot(col_live): that is rebuilt from the lane mask the same way -- scalar arithmetic on the uniform width)
+                        unsigned long long cm = 0ull;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) cm |= (width == kW || 16 * c + 4 * q + j < width) ? 0xFFFFull << (16 * q) : 0ull;
+                        live0[j] = __builtin_amdgcn_ballot_w64(v0 > 0.f) & cm;
+                        live1[j] = __builtin_amdgcn_ballot_w64(v1 > 0.f) & cm;
                     }
                 }
                 if constexpr (BITS) {           // the eight ballots go out as they are (see cnn3w_kernel<true>): [r][j] x 64 bits per (tile row, N-tile, c)
@@ -1056,9 +1062,16 @@ __global__ __launch_bounds__(768, 3) void cnn2w_kernel(const float* __restrict__
 #else
                     const uint32_t word = ballots_to_lanes(live0, live1);
 #endif
-                    if (lane < 16) {
-                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                        reinterpret_cast<uint32_t*>(bits)[((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16) + lane] = word;
+                    {   // the store's address = a scalar base + 4 x the lane index, the index recomputed here (mbcnt): kept across the tile
+                        // loop the compiler held `bits + lane` in a register pair it SPILLED at this kernel's 168 registers, and every
+                        // store waited (s_waitcnt vmcnt(0)) on a scratch reload of it
+                        uint32_t l16 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                        asm volatile("" : "+v"(l16));
+                        if (l16 < 16u) {
+                            const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                            uint32_t* wp = reinterpret_cast<uint32_t*>(bits) + ((((clip * kWTileRows + trow) * 4 + nt) * 2 + c) * 16);
+                            wp[l16] = word;
+                        }
                     }
                 }
             }
@@ -1589,8 +1602,11 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
                 const bool col_live = width == kW || 16 * c + 4 * kq + j < width;
                 pv[j] = col_live ? v0 + v1 : 0.f;
                 if constexpr (BITS) {           // bit (16 kq + pi) of the ballot <-> channel 16 nt + pi at column 16 c + 4 kq + j
-                    live0[j] = __builtin_amdgcn_ballot_w64(col_live && v0 > 0.f);
-                    live1[j] = __builtin_amdgcn_ballot_w64(col_live && v1 > 0.f);
+                    unsigned long long cm = 0ull;   // the column mask as scalar arithmetic (see cnn2w_kernel<2>)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cm |= (width == kW || 16 * c + 4 * q + j < width) ? 0xFFFFull << (16 * q) : 0ull;
+                    live0[j] = __builtin_amdgcn_ballot_w64(v0 > 0.f) & cm;
+                    live1[j] = __builtin_amdgcn_ballot_w64(v1 > 0.f) & cm;
                 }
             }
             if constexpr (BITS) pool += tree4(pv[0], pv[1], pv[2], pv[3]);     // training forward: at its 256-VGPR cap a second accumulator costs 6 spills
@@ -1613,9 +1629,14 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
 #else
                 const uint32_t word = ballots_to_lanes(live0, live1);
 #endif
-                if (lane < 16) {
-                    const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
-                    reinterpret_cast<uint32_t*>(bits3)[((((clip * kWTileRows + t) * 8 + nt) * 2 + c) * 16) + lane] = word;
+                {   // scalar base + 4 x a lane index recomputed here (see cnn2w_kernel<2>: no register pair held, or spilled, across the loop)
+                    uint32_t l16 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    asm volatile("" : "+v"(l16));
+                    if (l16 < 16u) {
+                        const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+                        uint32_t* wp = reinterpret_cast<uint32_t*>(bits3) + ((((clip * kWTileRows + t) * 8 + nt) * 2 + c) * 16);
+                        wp[l16] = word;
+                    }
                 }
             }
             // the next tile row goes into the OTHER buffer (last read in step g-1) between the two column halves: its loads have
