@@ -829,6 +829,12 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
     uint8_t mb[3];
     u32x4 dzr[DENSE ? 5 : 1];
     uint32_t sw_next = 0u;
+    // Every global address below is a UNIFORM base (scalar registers: clip, step) + a 32-bit per-thread offset.  Written as one 64-bit
+    // index per thread, the compiler kept `pointer + thread part` in register pairs across the step loop, spilled them at this kernel's
+    // 256 registers, and reloaded them from scratch in front of the loads -- with s_waitcnt vmcnt(0), i.e. every step first waited
+    // for the loads it had just issued to run ahead of its matrix work (scripts/isa_scratch.py lists such reloads).
+    const uint32_t mthread = uint32_t(mask2_byte(0, 0, mpos & 31, mcg));          // the thread's part of mask2_byte: N-tile, column, byte
+    const uint32_t dthread = uint32_t(dpos * 16 + dchunk);
     auto fill_load = [&](int gs) {                                 // issue the global loads early ...
         const int k = gs / kHSteps, s = gs - k * kHSteps;
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
@@ -837,16 +843,20 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int g = g0 + i <= g1 ? g0 + i : g1;
-                dzr[i] = reinterpret_cast<const u32x4*>(maskbits)[((clip * kTH + g) * kTW + dpos) * 16 + dchunk];
+                const u32x4* rowp = reinterpret_cast<const u32x4*>(maskbits) + (clip * kTH + g) * kTW * 16;
+                dzr[i] = rowp[dthread];
             }
         } else {
+            const uint8_t* clipp = maskbits + clip * (kTH / 2) * 512;              // mask2_byte(clip, 0, 0, 0)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int pos = mpos + 64 * i, g = g0 + (pos >> 5);
-                mb[i] = g <= g1 ? maskbits[mask2_byte(clip, g, pos & 31, mcg)] : uint8_t(0);
+                const uint32_t off = uint32_t((g >> 1) * 512 + (g & 1) * 32) + mthread;      // mask2_byte(clip, g, pos & 31, mcg) - the clip's base
+                mb[i] = g <= g1 ? clipp[off] : uint8_t(0);
             }
         }
-        if (tid < kHRows * kTW) sw_next = bits1[(clip * kTH + kHRows * s) * kTW + tid];
+        const uint32_t* s1p = bits1 + (clip * kTH + kHRows * s) * kTW;
+        if (tid < kHRows * kTW) sw_next = s1p[uint32_t(tid)];
     };
     auto fill_store = [&](int gs) {                                // ... and expand them into LDS behind the step's matrix work
         const int k = gs / kHSteps, s = gs - k * kHSteps;
