@@ -1527,6 +1527,9 @@ __global__ __launch_bounds__(512, 2) void cnn3w_kernel(const float* __restrict__
     auto fetch = [&](int g) {            // rows 2t-1 .. 2t+2 of step g (clip g / 40, tile row g % 40) -> registers
         const int k = g / kWTileRows, t = g - k * kWTileRows;
         const int64_t clip = int64_t(blockIdx.x) + int64_t(k) * gridDim.x;
+        // (tried: a uniform row pointer + the thread's 32-bit offset, which removes the two scratch reloads of the spilled pointer pair at
+        // the top of every step -- the register allocator then spills a WEIGHT fragment instead and reloads it inside the MFMA stream:
+        // 3.22 vs 3.12 ms for the 3-conv stack, scripts/isa_scratch.py shows both)
         const float* src = mid + (clip * kH * kW + lx) * 64 + 4 * lcg;
         pre_ap = apow2[clip];
 #pragma unroll
