@@ -28,8 +28,9 @@
 
 #include "ww_internal.h"
 
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 #include <emmintrin.h>
+#define WW_STREAMING_COPY 1
 #endif
 
 namespace ww {
@@ -177,6 +178,7 @@ namespace ww {
 static void copy_to_staging(uint8_t* dst, const uint8_t* src, size_t n) {
 #if !defined(__HIP_DEVICE_COMPILE__)
     size_t i = 0;
+#ifdef WW_STREAMING_COPY
     if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && n >= 256) {
         for (; i + 64 <= n; i += 64) {
             const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
@@ -190,6 +192,7 @@ static void copy_to_staging(uint8_t* dst, const uint8_t* src, size_t n) {
         }
         _mm_sfence();                                          // before the batch is handed on (the caller's thread starts the upload)
     }
+#endif
     std::memcpy(dst + i, src + i, n - i);
 #endif
 }
