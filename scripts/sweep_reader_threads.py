@@ -14,7 +14,7 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys
         pass
 res = {"host": info, "runs": []}
 print(json.dumps(info), flush=True)
-for rnd in range(2):
+for rnd in range(int(os.environ.get("SWEEP_ROUNDS", "2"))):
     for t in counts:
         r = bench_files.measure_file_pipeline(passes=int(os.environ.get("SWEEP_PASSES", "128")), threads=t, tmp_root=os.environ.get("SWEEP_TMP_ROOT"))
         row = {"round": rnd, "threads": t, "seconds": round(r["seconds"], 2), "host_cpus_used": r["host_cpus_used"], "quota_periods_throttled": r["quota_periods_throttled"], "clips_per_s": r["clips_per_s"], "host_read_only_clips_per_s": r["host_read_only_clips_per_s"],

@@ -48,7 +48,7 @@ def host_cpu_share() -> int:
 
 
 def default_threads() -> int:
-    """Host threads of a reader: this rank's CPU share (host_cpu_share), at most 32, or WW_READER_THREADS.  A reader thread is busy the
+    """Host threads of a reader: this rank's CPU share (host_cpu_share) less one when it is eight or more, at most 32, or WW_READER_THREADS.  A reader thread is busy the
     whole time a batch is being read (page cache warm: open / pread / close are CPU work, not waiting), so threads beyond the share
     only spend the cgroup's quota faster and are throttled for the rest of each 100 ms period: on an MI355X box (quota 16 CPUs), one
     stream over 0.5 M files, 12 / 16 / 24 / 32 / 48 threads fed the pipeline at 0.87-0.90 / 0.87-0.96 / 0.84-0.88 / 0.69-0.74 /
@@ -57,7 +57,10 @@ def default_threads() -> int:
     env = os.environ.get("WW_READER_THREADS")
     if env:
         return max(1, min(256, int(env)))
-    return max(1, min(32, host_cpu_share()))
+    share = host_cpu_share()
+    # one CPU of a larger share stays with the consumer (its Python, the HIP runtime's threads): 15 and 16 threads feed the pipeline alike
+    # on a 16-CPU quota (1.21-1.59 vs 1.27-1.38 M clips/s over four rounds), but 16 had quota periods throttled and 15 none
+    return max(1, min(32, share - 1 if share >= 8 else share))
 
 
 class EncodedPaths:
