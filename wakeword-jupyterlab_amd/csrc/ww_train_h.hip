@@ -771,6 +771,22 @@ __global__ void gp_max_kernel(const float* __restrict__ dpooled, float s, int n,
     if (lane == 0) gpmax[b] = m;
 }
 
+// Diagnostic build -DWW_DG_STAMPS (never shipped): every wave of workgroup 7 adds up the shader cycles (s_memtime) it spends in the step's phases --
+// 0 rebuild + issuing the next rows' loads, 1 the 72-MFMA loop, 2 the dW1 / db1 block, 3 expanding the next rows into LDS, 4 the barrier.
+#ifdef WW_DG_STAMPS
+__device__ unsigned long long g_dg_stamps[40];
+#define DSTAMP(i) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+    dst[i] += t__ - dlast; dlast = t__; } while (0)
+extern "C" __attribute__((visibility("default"))) int ww_debug_dg_stamps(unsigned long long* out) {
+    unsigned long long z[40] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dg_stamps), sizeof(z)) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dg_stamps), z, sizeof(z));
+    return 0;
+}
+#else
+#define DSTAMP(i) do {} while (0)
+#endif
+
 // maskbits: !DENSE the ReLU bit image of conv2;  DENSE the dz2 records.  gpmax: !DENSE max |gp| per clip;  DENSE dzs [n] (2^edz).  gp unused if DENSE.
 template <bool DENSE>
 __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __restrict__ mel, const uint8_t* __restrict__ maskbits,
@@ -935,10 +951,16 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
     if (total > 0) fill_store(0);
     __syncthreads();
     const char* abase = gring + (ln + 1) * L::kGRec + grp * 16;       // A: row = column ln of the m-tile, k = 8 channels of the lane group
+#ifdef WW_DG_STAMPS
+    unsigned long long dst[5] = {0, 0, 0, 0, 0}, dlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast) :: "memory");
+#endif
     for (int gs = 0; gs < total; ++gs) {
         const int k = gs / kHSteps, s = gs - k * kHSteps;
+        DSTAMP(4);                                                      // (behind the previous step's barrier)
         if (s == 0) rebuild(k);
         if (gs + 1 < total) fill_load(gs + 1);
+        DSTAMP(0);
         const int y = kHRows * s + rg;
         f32x4 acc[2];
 #pragma unroll
@@ -982,6 +1004,7 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
             if constexpr (DENSE) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[it % RING], bh[ks], acc[mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        DSTAMP(1);
         // epilogue: D register j <-> column 16 mt + 4 grp + j, lane & 15 <-> ci = 16 nt + ln.  That IS the A-operand layout of a
         // 16x16x32 block (m = ci, the lane group's eight k = its eight columns 4 grp + 0..3, 16 + 4 grp + 0..3), so the row's
         // dW1 / db1 contribution is one k = 32 block: A = dz1 2^-down as hi + lo, B[k][n = tap] = mel at the same eight columns
@@ -1020,9 +1043,16 @@ __global__ __launch_bounds__(512, 2) void conv2_dgrad_h_kernel(const float* __re
                 cacc[j] = 0.f;
             }
         }
+        DSTAMP(2);
         if (gs + 1 < total) fill_store(gs + 1);
+        DSTAMP(3);
         __syncthreads();
     }
+    DSTAMP(4);
+#ifdef WW_DG_STAMPS
+    if (!DENSE && blockIdx.x == 7 && lane == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_dg_stamps[wave * 5 + i], dst[i]);
+#endif
     // the four row waves of a ci tile, in fixed order -> this workgroup's partial
     double* red = reinterpret_cast<double*>(ldsb);                   // [8 waves][4][64]
 #pragma unroll
